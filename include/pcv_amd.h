@@ -1,0 +1,133 @@
+/*
+ * pcv_amd.h - C ABI of the MI355X (gfx950) conv-net inference hot path for the pytorchcv model zoo.
+ *
+ * The reference (osmr/pytorchcv 0.0.73) is pure Python: every op on its inference path reaches PyTorch ATen
+ * through `torch.nn` modules. This library replaces those ATen ops, for the path only, with hand-written
+ * HIP kernels. Each entry point below names the reference call site whose ATen op(s) it replaces
+ * (paths relative to the reference root); `INTEGRATION.md` shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *   - extern "C", plain C types, no C++/torch types; every function returns 0 on success or a negative
+ *     pcv_status; `pcv_last_error(ctx)` gives the text. The library never throws and never calls back.
+ *   - All data pointers are DEVICE pointers borrowed for the duration of the call. Work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the null stream) and the call returns without
+ *     synchronising. `pcv_conv_pack`/`pcv_dwconv_pack` additionally upload a small host-built table with a
+ *     synchronous copy: they are weight-load-time functions, not hot-path ones.
+ *   - Activations are NHWC ("pixels x channels", channels contiguous) in `dtype`; the ABI never sees NCHW
+ *     except in the two layout-conversion entry points. fp32 is only used for scale/shift/bias/gates/logits.
+ *   - A context belongs to one device; the library is re-entrant per context.
+ */
+#ifndef PCV_AMD_H
+#define PCV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCV_ABI_VERSION 1
+
+typedef struct pcv_ctx pcv_ctx;
+
+typedef enum pcv_status {
+    PCV_OK = 0,
+    PCV_ERR_INVALID = -1,     /* bad argument / unsupported configuration (never silently wrong) */
+    PCV_ERR_HIP = -2,         /* a HIP runtime call failed; text in pcv_last_error */
+    PCV_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    PCV_ERR_TOO_LARGE = -4    /* a tensor exceeds the 2 GiB addressing window of one launch; split the batch */
+} pcv_status;
+
+typedef enum pcv_dtype { PCV_F32 = 0, PCV_BF16 = 1, PCV_F16 = 2 } pcv_dtype;
+
+/* activ.py:50-81,117-132 (relu, relu6, sigmoid) and activ.py:16-47 (swish, hsigmoid, hswish) */
+typedef enum pcv_act {
+    PCV_ACT_NONE = 0, PCV_ACT_RELU = 1, PCV_ACT_RELU6 = 2, PCV_ACT_SIGMOID = 3,
+    PCV_ACT_SWISH = 4, PCV_ACT_HSIGMOID = 5, PCV_ACT_HSWISH = 6
+} pcv_act;
+
+/*
+ * One fused ConvBlock launch: y = post_act( act( conv(x) * scale + shift ) + residual ).
+ * Replaces Conv2d + BatchNorm2d(eval) + activation of ConvBlock.forward (pytorchcv/models/common/conv.py:278-286,
+ * incl. the explicit ZeroPad2d of conv.py:245-249 through the four pad fields) and, when has_residual, the
+ * `x + identity` + activation that follows the block in the unit (resnet.py:227-228, resnext.py:114-115,
+ * mobilenetv2.py:69-70).
+ */
+typedef struct pcv_conv_desc {
+    int32_t N, H, W;               /* input batch and logical spatial size */
+    int32_t Cin, Cout;             /* logical channels (all groups) */
+    int32_t kh, kw;
+    int32_t stride_h, stride_w;
+    int32_t pad_t, pad_l, pad_b, pad_r;
+    int32_t dil_h, dil_w;
+    int32_t groups;
+    int32_t act;                   /* pcv_act after scale/shift */
+    int32_t post_act;              /* pcv_act after the residual add */
+    int32_t has_residual;
+    int32_t dtype;                 /* pcv_dtype of x, packed weights, residual */
+    int32_t out_dtype;             /* pcv_dtype of y: dtype, or PCV_F32 (classifier logits) */
+    int32_t x_cpitch;              /* channel pitch of x in elements: Cin, or 4 / round-up-8 for a padded stem input */
+    int32_t x_wpitch;              /* row pitch of x in pixels: W, or W rounded up to even for a padded stem input */
+} pcv_conv_desc;
+
+/* ---- context ------------------------------------------------------------------------------------------ */
+int pcv_abi_version(void);
+int pcv_create(pcv_ctx** out, int device);
+int pcv_destroy(pcv_ctx* ctx);
+const char* pcv_last_error(const pcv_ctx* ctx);     /* ctx may be NULL: returns the last creation error */
+
+/* ---- layout: the only NCHW-facing calls ---------------------------------------------------------------- */
+/* x: fp32 NCHW [N,C,H,W] (what callers hand to `net(x)`, resnet.py:333) -> y: NHWC [N,H,wpitch,cpitch] in dtype,
+ * pad channels / pad columns zero-filled. */
+int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H, int W,
+                     int cpitch, int wpitch, int dtype, void* stream);
+/* x: NHWC [N,H,W,C] in dtype -> y: fp32 NCHW (block-level drop-in use; not on the whole-net hot path). */
+int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
+
+/* ---- weights (load time) ------------------------------------------------------------------------------- */
+/* Size of the packed-weight blob of a dense or grouped conv (groups < Cin). */
+int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);
+/* w: fp32 OIHW [Cout, Cin/groups, kh, kw] exactly as `conv.weight` in the reference state_dict (conv.py:250-258)
+ * -> packed: K-major, MFMA-row-ordered blob in d->dtype (layout in DESIGN.md). N/H/W of d are ignored. */
+int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream);
+/* Depthwise (groups == Cin == Cout, conv.py:437-473): w fp32 [C,1,kh,kw] -> packed [kh*kw][C] in dtype. */
+int pcv_dwconv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);
+int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream);
+/* Eval-mode BatchNorm2d (common/norm.py:34-50) folded to fp32 scale/shift; any of gamma..var NULL means "no BN"
+ * (scale 1, shift 0); conv_bias (conv.bias, may be NULL) is folded in: shift += bias * scale. */
+int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, const float* mean, const float* var,
+                float eps, const float* conv_bias, float* scale, float* shift, void* stream);
+
+/* ---- hot path ------------------------------------------------------------------------------------------ */
+/* Dense / grouped implicit-GEMM convolution on MFMA, fused epilogue. x NHWC [N,H,x_wpitch,x_cpitch];
+ * residual (or NULL) and y NHWC [N,Ho,Wo,Cout]. */
+int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
+                     const float* scale, const float* shift, const void* residual, void* y, void* stream);
+/* Depthwise direct convolution, fused epilogue (same contract). */
+int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
+                       const float* scale, const float* shift, const void* residual, void* y, void* stream);
+/* nn.MaxPool2d(k, s, p) of ResInitBlock (resnet.py:255-258); -inf padding, floor output size. */
+int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p,
+                  int dtype, void* stream);
+/* nn.AvgPool2d(k, stride=s), no padding (resnet.py:316-318, mobilenetv2.py:134-136); k == H == W is the
+ * global-average-pool of the classifier tail. fp32 accumulation. */
+int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s,
+                  int dtype, int out_dtype, void* stream);
+/* nn.Linear (resnet.py:320-322,336) / bias-free 1x1 classifier conv (mobilenetv2.py:138-141,154):
+ * y[N,Cout] (out_dtype) = x[N,Cin] (dtype) . W^T + bias. `packed` comes from pcv_conv_pack with kh=kw=1. */
+int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* bias, void* y,
+                  int N, int Cin, int Cout, int dtype, int out_dtype, void* stream);
+/* SEBlock (common/att.py:94-105): squeeze = AdaptiveAvgPool2d(1) -> mean fp32 [N,C]. */
+int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int C, int dtype, void* stream);
+/* gate[N,C] = out_act(W2 . mid_act(W1 . mean + b1) + b2); W1 fp32 [M,C], W2 fp32 [C,M] (att.py:76-92). */
+int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* gate, int N, int C, int M, int mid_act, int out_act, void* stream);
+/* y = post_act(x * gate[n,c] + residual) (att.py:104 + seresnet.py:69-71); residual may be NULL. */
+int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y,
+                 int N, int HW, int C, int post_act, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCV_AMD_H */

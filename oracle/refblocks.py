@@ -1,0 +1,82 @@
+"""
+    ORACLE - test infrastructure, not product code.
+
+    Block-level CPU restatement: forward of one reference block (by constructor name + kwargs, as listed in
+    tests/golden/cases.py) over a state_dict, in reference-exact fp32 mode or quantisation-matched 16-bit mode
+    (see oracle/refnet.py). Reference lines: common/conv.py:204-543 (ConvBlock and factories), common/att.py:94-105
+    (SEBlock), resnet.py:143-263 (ResUnit, ResInitBlock), mobilenetv2.py:16-71 (LinearBottleneck), resnext.py:17-116
+    (ResNeXtUnit), seresnet.py:17-72 (SEResUnit).
+"""
+
+__all__ = ['block_forward']
+
+import torch
+import torch.nn.functional as F
+from .refnet import Quant, conv_block, se_block, _res_body
+
+_KSIZE = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv5x5_block": (5, 2), "conv7x7_block": (7, 3),
+          "dwconv3x3_block": (3, 1), "dwconv5x5_block": (5, 2)}
+
+
+def _act_name(a, default="relu"):
+    if a is None:
+        return None
+    if isinstance(a, str):
+        return a
+    return default
+
+
+def _conv_kind(kind, kw, sd, x, q, prefix=""):
+    kw = dict(kw)
+    if kind == "ConvBlock":
+        k = kw["kernel_size"]
+        pad = kw.get("padding", 0)
+    else:
+        k, pad = _KSIZE[kind]
+        pad = kw.get("padding", pad)
+    groups = kw.get("groups", 1)
+    if kind.startswith("dwconv"):
+        groups = kw["out_channels"]
+    act = _act_name(kw["activation"]) if "activation" in kw else "relu"
+    normalize = not ("normalization" in kw and kw["normalization"] is None)
+    if isinstance(pad, (list, tuple)) and len(pad) == 4:
+        pad = tuple(pad)
+    return conv_block(sd, prefix, x, stride=kw.get("stride", 1), padding=pad, dilation=kw.get("dilation", 1),
+                      groups=groups, act=act, q=q, normalize=normalize)
+
+
+def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str | None = None) -> torch.Tensor:
+    q = Quant(quant)
+    kw = dict(kwargs)
+    with torch.no_grad():
+        x = q.r(x.float())
+        if kind in _KSIZE or kind == "ConvBlock":
+            return _conv_kind(kind, kw, sd, x, q)
+        if kind == "SEBlock":
+            return se_block(sd, "", x, q=q)
+        if kind == "ResInitBlock":
+            y = conv_block(sd, "conv.", x, stride=2, padding=3, q=q)
+            return F.max_pool2d(y, kernel_size=3, stride=2, padding=1)
+        if kind in ("ResUnit", "SEResUnit"):
+            stride = kw.get("stride", 1)
+            resize = (kw["in_channels"] != kw["out_channels"]) or (stride != 1)
+            identity = conv_block(sd, "identity_conv.", x, stride=stride, act=None, q=q) if resize else x
+            if kind == "SEResUnit":
+                y = _res_body(sd, "body.", x, stride, kw["bottleneck"], kw["conv1_stride"], q, None, None)
+                return se_block(sd, "se.", y, q=q, residual=identity, post_act="relu")
+            return _res_body(sd, "body.", x, stride, kw.get("bottleneck", True), kw.get("conv1_stride", False), q,
+                             identity, "relu")
+        if kind == "LinearBottleneck":
+            stride = kw["stride"]
+            residual = x if (kw["in_channels"] == kw["out_channels"] and stride == 1) else None
+            y = conv_block(sd, "conv1.", x, act="relu6", q=q)
+            y = conv_block(sd, "conv2.", y, stride=stride, padding=1, groups=y.shape[1], act="relu6", q=q)
+            return conv_block(sd, "conv3.", y, act=None, q=q, residual=residual)
+        if kind == "ResNeXtUnit":
+            stride = kw["stride"]
+            resize = (kw["in_channels"] != kw["out_channels"]) or (stride != 1)
+            identity = conv_block(sd, "identity_conv.", x, stride=stride, act=None, q=q) if resize else x
+            y = conv_block(sd, "body.conv1.", x, q=q)
+            y = conv_block(sd, "body.conv2.", y, stride=stride, padding=1, groups=kw["cardinality"], q=q)
+            return conv_block(sd, "body.conv3.", y, act=None, q=q, residual=identity, post_act="relu")
+    raise NotImplementedError(kind)

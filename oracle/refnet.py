@@ -1,0 +1,306 @@
+"""
+    ORACLE - test infrastructure, not product code.
+
+    CPU restatement of the reference's conv-net inference path (osmr/pytorchcv 0.0.73) as pure
+    functions over a `state_dict`. Only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline`
+    leg of `bench.py` may import this package; `pytorchcv_amd/` never does.
+
+    Parity pin: the reference's own tests hold no tensor values ("parity
+    unpinned" by the reference), so this restatement is pinned against outputs of the reference
+    itself, imported in the build container by `tests/golden/make_golden.py`, and frozen as the
+    fixtures under `tests/golden/` (`tests/test_oracle_golden.py` checks them, <= 1e-5).
+
+    Every function cites the reference lines it follows (paths relative to the reference root).
+    Arithmetic is delegated to the same third-party library the reference uses (torch, CPU, fp32);
+    `oracle/cref.c` is an ATen-free restatement of the individual ops used to cross-check it.
+
+    Two modes:
+      * quant=None      - the reference semantics exactly: unfused conv -> batch_norm -> activation.
+      * quant="bf16"/"fp16" - "quantisation-matched" restatement of the fused MI355X pipeline: weights
+        and every tensor the GPU path stores to HBM are rounded to the 16-bit type at the same points,
+        accumulation and the BN/activation/residual epilogue stay fp32.
+"""
+
+__all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
+           'seresnet_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
+
+import math
+import torch
+import torch.nn.functional as F
+
+
+class Quant(object):
+    """Rounding points of the fused 16-bit pipeline (identity when dtype is None)."""
+    def __init__(self, dtype: str | None):
+        self.dtype = {None: None, "fp32": None, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+
+    def r(self, t: torch.Tensor) -> torch.Tensor:
+        if self.dtype is None:
+            return t
+        return t.to(self.dtype).to(torch.float32)
+
+    @property
+    def on(self) -> bool:
+        return self.dtype is not None
+
+
+def _act(x: torch.Tensor, act: str | None) -> torch.Tensor:
+    # pytorchcv/models/common/activ.py:50-81 (relu, relu6), :117-132 (sigmoid)
+    if act is None:
+        return x
+    if act == "relu":
+        return F.relu(x)
+    if act == "relu6":
+        return F.relu6(x)
+    if act == "sigmoid":
+        return torch.sigmoid(x)
+    raise NotImplementedError(act)
+
+
+def fold_bn(sd: dict, prefix: str, eps: float = 1e-5):
+    """Eval-mode BatchNorm2d (common/norm.py:34-50) as per-channel scale/shift."""
+    g = sd[prefix + "weight"].float()
+    b = sd[prefix + "bias"].float()
+    m = sd[prefix + "running_mean"].float()
+    v = sd[prefix + "running_var"].float()
+    scale = g / torch.sqrt(v + eps)
+    shift = b - m * scale
+    return scale, shift
+
+
+def conv_block(sd: dict, prefix: str, x: torch.Tensor, stride=1, padding=0, dilation=1, groups=1,
+               act: str | None = "relu", q: Quant | None = None, residual: torch.Tensor | None = None,
+               post_act: str | None = None, eps: float = 1e-5, normalize: bool = True) -> torch.Tensor:
+    """
+    ConvBlock.forward, pytorchcv/models/common/conv.py:278-286: [ZeroPad2d] -> Conv2d -> [BN] -> [act].
+    `residual`/`post_act` restate the add + activation that follows the block in the unit
+    (resnet.py:227-228, mobilenetv2.py:69-70), which the GPU path fuses into the epilogue.
+    """
+    q = q or Quant(None)
+    w = sd[prefix + "conv.weight"].float()
+    bias = sd.get(prefix + "conv.bias", None)
+    if isinstance(padding, (list, tuple)) and len(padding) == 4:
+        # conv.py:245-249: 4-tuple padding is an explicit ZeroPad2d (left, right, top, bottom)
+        x = F.pad(x, padding)
+        padding = 0
+    if q.on:
+        y = F.conv2d(x, q.r(w), None, stride, padding, dilation, groups)
+        if normalize:
+            scale, shift = fold_bn(sd, prefix + "bn.", eps)
+            if bias is not None:
+                shift = shift + bias.float() * scale
+        else:
+            scale = torch.ones(w.shape[0])
+            shift = bias.float() if bias is not None else torch.zeros(w.shape[0])
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.conv2d(x, w, bias, stride, padding, dilation, groups)
+        if normalize:
+            p = prefix + "bn."
+            y = F.batch_norm(y, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"],
+                             False, 0.0, eps)
+    y = _act(y, act)
+    if residual is not None:
+        y = y + residual
+    y = _act(y, post_act)
+    return q.r(y)
+
+
+def se_block(sd: dict, prefix: str, x: torch.Tensor, q: Quant | None = None,
+             residual: torch.Tensor | None = None, post_act: str | None = None) -> torch.Tensor:
+    """
+    SEBlock.forward, pytorchcv/models/common/att.py:94-105 (use_conv=True): AdaptiveAvgPool2d(1) ->
+    1x1 conv + bias -> ReLU -> 1x1 conv + bias -> Sigmoid -> x * w.  The excitation runs in fp32 on
+    the GPU path too (tiny), so only the stored result is rounded.
+    """
+    q = q or Quant(None)
+    w = x.mean(dim=(2, 3), keepdim=True)
+    w = F.conv2d(w, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"])
+    w = F.relu(w)
+    w = F.conv2d(w, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])
+    w = torch.sigmoid(w)
+    y = x * w
+    if residual is not None:
+        y = y + residual
+    y = _act(y, post_act)
+    return q.r(y)
+
+
+def _tap(taps, name, t):
+    if taps is not None:
+        taps[name] = t
+
+
+def _res_init_block(sd, x, q):
+    # ResInitBlock, resnet.py:232-263: conv7x7_block(stride 2, pad 3) + MaxPool2d(3, 2, 1)
+    x = conv_block(sd, "features.init_block.conv.", x, stride=2, padding=3, q=q)
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def _classifier(sd, x, q):
+    # resnet.py:316-322,333-337: AvgPool2d(7, stride=1) -> view -> Linear
+    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
+    x = x.view(x.size(0), -1)
+    return F.linear(x, q.r(sd["output.weight"].float()), sd["output.bias"].float())
+
+
+def _res_layers(blocks: int, bottleneck: bool | None):
+    # get_resnet, resnet.py:373-419
+    if bottleneck is None:
+        bottleneck = (blocks >= 50)
+    table = {10: [1, 1, 1, 1], 12: [2, 1, 1, 1], 16: [2, 2, 2, 1], 18: [2, 2, 2, 2], 34: [3, 4, 6, 3],
+             50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3], 200: [3, 24, 36, 3]}
+    if blocks == 14:
+        layers = [1, 1, 1, 1] if bottleneck else [2, 2, 1, 1]
+    elif blocks == 26:
+        layers = [2, 2, 2, 2] if bottleneck else [3, 3, 3, 3]
+    elif blocks == 38 and bottleneck:
+        layers = [3, 3, 3, 3]
+    elif blocks in table:
+        layers = table[blocks]
+    else:
+        raise ValueError("Unsupported ResNet with number of blocks: {}".format(blocks))
+    cpl = [64, 128, 256, 512]
+    if bottleneck:
+        cpl = [c * 4 for c in cpl]
+    channels = [[c] * n for c, n in zip(cpl, layers)]
+    return channels, bottleneck
+
+
+def _res_body(sd, p, x, stride, bottleneck, conv1_stride, q, residual, post_act):
+    if bottleneck:
+        # ResBottleneck, resnet.py:69-140
+        y = conv_block(sd, p + "conv1.", x, stride=(stride if conv1_stride else 1), q=q)
+        y = conv_block(sd, p + "conv2.", y, stride=(1 if conv1_stride else stride), padding=1, q=q)
+        return conv_block(sd, p + "conv3.", y, act=None, q=q, residual=residual, post_act=post_act)
+    # ResBlock, resnet.py:19-66
+    y = conv_block(sd, p + "conv1.", x, stride=stride, padding=1, q=q)
+    return conv_block(sd, p + "conv2.", y, padding=1, act=None, q=q, residual=residual, post_act=post_act)
+
+
+def resnet_forward(sd, x, blocks, bottleneck=None, conv1_stride=True, q=None, taps=None, se=False):
+    """ResNet.forward (resnet.py:333-337) / SEResNet.forward (seresnet.py:134-138) with ResUnit
+    (resnet.py:221-229) / SEResUnit (seresnet.py:63-72)."""
+    q = q or Quant(None)
+    channels, bottleneck = _res_layers(blocks, bottleneck)
+    x = q.r(x)
+    x = _res_init_block(sd, x, q)
+    _tap(taps, "init_block", x)
+    in_ch = 64
+    for i, cps in enumerate(channels):
+        for j, out_ch in enumerate(cps):
+            stride = 2 if (j == 0) and (i != 0) else 1
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            if (in_ch != out_ch) or (stride != 1):
+                identity = conv_block(sd, p + "identity_conv.", x, stride=stride, act=None, q=q)
+            else:
+                identity = x
+            if se:
+                y = _res_body(sd, p + "body.", x, stride, bottleneck, conv1_stride, q, None, None)
+                x = se_block(sd, p + "se.", y, q=q, residual=identity, post_act="relu")
+            else:
+                x = _res_body(sd, p + "body.", x, stride, bottleneck, conv1_stride, q, identity, "relu")
+            in_ch = out_ch
+        _tap(taps, "stage{}".format(i + 1), x)
+    return _classifier(sd, x, q)
+
+
+def seresnet_forward(sd, x, blocks, q=None, taps=None):
+    return resnet_forward(sd, x, blocks, q=q, taps=taps, se=True)
+
+
+def resnext_forward(sd, x, blocks, cardinality, bottleneck_width, q=None, taps=None):
+    """ResNeXt.forward (resnext.py:186-190); ResNeXtUnit (resnext.py:108-116); ResNeXtBottleneck
+    (resnext.py:41-65): stride sits on the grouped 3x3."""
+    q = q or Quant(None)
+    layers = {14: [1, 1, 1, 1], 26: [2, 2, 2, 2], 38: [3, 3, 3, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}[blocks]
+    channels = [[c] * n for c, n in zip([256, 512, 1024, 2048], layers)]
+    x = q.r(x)
+    x = _res_init_block(sd, x, q)
+    _tap(taps, "init_block", x)
+    in_ch = 64
+    for i, cps in enumerate(channels):
+        for j, out_ch in enumerate(cps):
+            stride = 2 if (j == 0) and (i != 0) else 1
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            if (in_ch != out_ch) or (stride != 1):
+                identity = conv_block(sd, p + "identity_conv.", x, stride=stride, act=None, q=q)
+            else:
+                identity = x
+            y = conv_block(sd, p + "body.conv1.", x, q=q)
+            y = conv_block(sd, p + "body.conv2.", y, stride=stride, padding=1, groups=cardinality, q=q)
+            x = conv_block(sd, p + "body.conv3.", y, act=None, q=q, residual=identity, post_act="relu")
+            in_ch = out_ch
+        _tap(taps, "stage{}".format(i + 1), x)
+    return _classifier(sd, x, q)
+
+
+def mobilenetv2_forward(sd, x, width_scale=1.0, q=None, taps=None):
+    """MobileNetV2.forward (mobilenetv2.py:152-156); LinearBottleneck (mobilenetv2.py:62-71);
+    channel plan of get_mobilenetv2 (mobilenetv2.py:183-203)."""
+    q = q or Quant(None)
+    layers = [1, 2, 3, 4, 3, 3, 1]
+    downsample = [0, 1, 1, 1, 0, 1, 0]
+    cpl = [16, 24, 32, 64, 96, 160, 320]
+    channels = [[]]
+    for c, n, d in zip(cpl, layers, downsample):
+        if d != 0:
+            channels = channels + [[c] * n]
+        else:
+            channels = channels[:-1] + [channels[-1] + [c] * n]
+    init_ch, final_ch = 32, 1280
+    if width_scale != 1.0:
+        channels = [[int(c * width_scale) for c in ci] for ci in channels]
+        init_ch = int(init_ch * width_scale)
+        if width_scale > 1.0:
+            final_ch = int(final_ch * width_scale)
+    x = q.r(x)
+    x = conv_block(sd, "features.init_block.", x, stride=2, padding=1, act="relu6", q=q)
+    _tap(taps, "init_block", x)
+    in_ch = init_ch
+    for i, cps in enumerate(channels):
+        for j, out_ch in enumerate(cps):
+            stride = 2 if (j == 0) and (i != 0) else 1
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            residual = x if (in_ch == out_ch and stride == 1) else None
+            y = conv_block(sd, p + "conv1.", x, act="relu6", q=q)     # expansion (always present for _w1)
+            mid = y.shape[1]
+            y = conv_block(sd, p + "conv2.", y, stride=stride, padding=1, groups=mid, act="relu6", q=q)
+            x = conv_block(sd, p + "conv3.", y, act=None, q=q, residual=residual)
+            in_ch = out_ch
+        _tap(taps, "stage{}".format(i + 1), x)
+    x = conv_block(sd, "features.final_block.", x, act="relu6", q=q)
+    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
+    # mobilenetv2.py:138-141,154-155: bias-free 1x1 conv classifier, then view
+    x = F.conv2d(x, q.r(sd["output.weight"].float()))
+    return x.view(x.size(0), -1)
+
+
+MODEL_ARCH = {
+    "resnet18": ("resnet", dict(blocks=18)),
+    "resnet34": ("resnet", dict(blocks=34)),
+    "resnet50": ("resnet", dict(blocks=50)),
+    "resnet50b": ("resnet", dict(blocks=50, conv1_stride=False)),
+    "resnet101": ("resnet", dict(blocks=101)),
+    "resnet152": ("resnet", dict(blocks=152)),
+    "mobilenetv2_w1": ("mobilenetv2", dict(width_scale=1.0)),
+    "mobilenetv2_w3d4": ("mobilenetv2", dict(width_scale=0.75)),
+    "mobilenetv2_wd2": ("mobilenetv2", dict(width_scale=0.5)),
+    "mobilenetv2_wd4": ("mobilenetv2", dict(width_scale=0.25)),
+    "resnext50_32x4d": ("resnext", dict(blocks=50, cardinality=32, bottleneck_width=4)),
+    "resnext101_32x4d": ("resnext", dict(blocks=101, cardinality=32, bottleneck_width=4)),
+    "resnext101_64x4d": ("resnext", dict(blocks=101, cardinality=64, bottleneck_width=4)),
+    "seresnet18": ("seresnet", dict(blocks=18)),
+    "seresnet50": ("seresnet", dict(blocks=50)),
+    "seresnet101": ("seresnet", dict(blocks=101)),
+}
+
+_FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
+           "seresnet": seresnet_forward}
+
+
+def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):
+    """CPU forward of `model_name` (`x`: NCHW fp32 -> [N, num_classes] fp32)."""
+    family, kw = MODEL_ARCH[model_name]
+    with torch.no_grad():
+        return _FAMILY[family](sd, x.float(), q=Quant(quant), taps=taps, **kw)

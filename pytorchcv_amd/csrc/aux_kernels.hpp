@@ -1,0 +1,271 @@
+// aux_kernels.hpp - the small HBM-bound kernels around the convolutions: layout conversion, weight packing,
+// BN folding, max/avg pooling, SE squeeze / excite / scale. All NHWC, 8 channels (16 bytes at 16-bit) per thread.
+#pragma once
+#include "pcv_common.hpp"
+#include "dwconv.hpp"   // load8 / store8
+
+// ---- NCHW fp32 -> NHWC(cpitch, wpitch) --------------------------------------------------------------------
+// What `net(x)` receives in the reference (resnet.py:333) is NCHW fp32; the hot path is NHWC. One thread = one
+// output pixel x up to 8 channels; reads are coalesced along W per channel plane, pad channels/columns get zeros.
+template <int OT>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, void* __restrict__ y,
+                                                          int N, int C, int H, int W, int cpitch, int wpitch) {
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;       // over N*H*wpitch
+    const long npix = (long)N * H * wpitch;
+    if (pix >= npix) return;
+    const int c0 = blockIdx.y * 8;
+    const int w = (int)(pix % wpitch);
+    const long nh = pix / wpitch;
+    const int h = (int)(nh % H);
+    const int n = (int)(nh / H);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        v[e] = (c < C && w < W) ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
+    }
+    const size_t eoff = (size_t)pix * cpitch + c0;
+    if (cpitch - c0 >= 8) {
+        store8<OT>(y, eoff, v);
+    } else if (cpitch - c0 == 4) {
+        if constexpr (OT == PCV_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + eoff) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+            u32x2 o = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(y) + eoff) = o;
+        }
+    } else {
+        for (int e = 0; e < cpitch - c0; ++e) store_elem<OT>(y, eoff + e, v[e]);
+    }
+}
+
+// NHWC [N,H,W,C] -> NCHW fp32 (block-level API only)
+template <int DT>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y,
+                                                          int N, int C, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;         // over N*C*H*W, w fastest
+    const long total = (long)N * C * H * W;
+    if (i >= total) return;
+    const int w = (int)(i % W);
+    long t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int n = (int)(t / C);
+    y[i] = load_elem<DT>(x, (((size_t)n * H + h) * W + w) * C + c);
+}
+
+// ---- weight packing (load time) ----------------------------------------------------------------------------
+// ksrc[k] = (c_in_block | (r*kw+q) << 16) or 0xFFFFFFFF. Row position p of the packed matrix holds the output
+// channel 32*(p>>5) + 8*((p&15)>>2) + 4*((p>>4)&1) + (p&3) of its group-block (MFMA accumulator-row order, so that
+// the conv epilogue writes 8 consecutive channels per lane).
+struct PackParams {
+    const float* w;          // OIHW fp32
+    void* out;               // [ngb][wrows][Kpad]
+    const uint32_t* ksrc;    // [Kpad]
+    int ngb, wrows, Kpad;
+    int cout_blk, cin_blk;   // channels per group-block
+    int Cg_in, Cg_out;       // channels per convolution group
+    int khkw;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const PackParams p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)p.ngb * p.wrows * p.Kpad;
+    if (i >= total) return;
+    const int k = (int)(i % p.Kpad);
+    long t = i / p.Kpad;
+    const int pos = (int)(t % p.wrows);
+    const int gb = (int)(t / p.wrows);
+    const int ch = 32 * (pos >> 5) + 8 * ((pos & 15) >> 2) + 4 * ((pos >> 4) & 1) + (pos & 3);
+    float v = 0.f;
+    const uint32_t ks = p.ksrc[k];
+    if (ch < p.cout_blk && ks != 0xFFFFFFFFu) {
+        const int och = gb * p.cout_blk + ch;
+        const int cin = gb * p.cin_blk + (int)(ks & 0xFFFFu);
+        const int g = och / p.Cg_out;
+        const int cl = cin - g * p.Cg_in;
+        if (cl >= 0 && cl < p.Cg_in) v = p.w[((size_t)och * p.Cg_in + cl) * p.khkw + (ks >> 16)];
+    }
+    store_elem<DT>(p.out, (size_t)i, v);
+}
+
+// depthwise: w fp32 [C,1,kh,kw] -> [kh*kw][C]
+template <int DT>
+__global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ w, void* __restrict__ out, int C, int khkw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * khkw) return;
+    const int c = i % C, k = i / C;
+    store_elem<DT>(out, (size_t)i, w[(size_t)c * khkw + k]);
+}
+
+// eval-mode BatchNorm2d (common/norm.py:34-50) folded to scale/shift, conv bias folded in
+__global__ __launch_bounds__(256) void bn_fold_kernel(int C, const float* gamma, const float* beta, const float* mean,
+                                                     const float* var, float eps, const float* bias, float* scale,
+                                                     float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 1.f, h = 0.f;
+    if (gamma != nullptr) {
+        s = gamma[c] / sqrtf(var[c] + eps);
+        h = beta[c] - mean[c] * s;
+    }
+    if (bias != nullptr) h += bias[c] * s;
+    scale[c] = s;
+    shift[c] = h;
+}
+
+// ---- pooling ----------------------------------------------------------------------------------------------
+// nn.MaxPool2d(k, s, p) (resnet.py:255-258): -inf padding, floor output size.
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ x, void* __restrict__ y, int N, int H, int W,
+                                                     int C, int Ho, int Wo, int k, int s, int pad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int C8 = C / 8;
+    const long total = (long)N * Ho * Wo * C8;
+    if (i >= total) return;
+    const int c0 = (int)(i % C8) * 8;
+    long t = i / C8;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int r = 0; r < k; ++r) {
+        const int hi = ho * s - pad + r;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        for (int q = 0; q < k; ++q) {
+            const int wi = wo * s - pad + q;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            float v[8];
+            load8<DT>(x, (((size_t)n * H + hi) * W + wi) * C + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+    }
+    store8<DT>(y, (size_t)i * 8, m);
+}
+
+// nn.AvgPool2d(k, stride=s) without padding (resnet.py:316-318); general (non-global) case
+template <int DT, int OT>
+__global__ __launch_bounds__(256) void avgpool_kernel(const void* __restrict__ x, void* __restrict__ y, int N, int H, int W,
+                                                     int C, int Ho, int Wo, int k, int s) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int C8 = C / 8;
+    const long total = (long)N * Ho * Wo * C8;
+    if (i >= total) return;
+    const int c0 = (int)(i % C8) * 8;
+    long t = i / C8;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int r = 0; r < k; ++r)
+        for (int q = 0; q < k; ++q) {
+            float v[8];
+            load8<DT>(x, (((size_t)n * H + ho * s + r) * W + wo * s + q) * C + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += v[e];
+        }
+    const float inv = 1.f / (float)(k * k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= inv;
+    store8<OT>(y, (size_t)i * 8, a);
+}
+
+// Spatial mean over HW positions: global average pool (AvgPool2d(7) on a 7x7 map, resnet.py:316-318) and the SE
+// squeeze (AdaptiveAvgPool2d(1), att.py:72). Block = (image n, slab of 256 channels); 32 lanes x 8 channels across,
+// 8 thread-rows striding over HW, fp32 partials reduced through LDS.
+template <int DT, int OT>
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const void* __restrict__ x, void* __restrict__ y, int HW, int C) {
+    __shared__ float part[8][32][8];
+    const int n = blockIdx.x;
+    const int lane32 = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const int c0 = (blockIdx.y * 32 + lane32) * 8;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (c0 < C) {
+        for (int hw = row; hw < HW; hw += 8) {
+            float v[8];
+            load8<DT>(x, ((size_t)n * HW + hw) * C + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[row][lane32][e] = a[e];
+    __syncthreads();
+    if (row == 0 && c0 < C) {
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += part[r][lane32][e];
+            a[e] = s * inv;
+        }
+        store8<OT>(y, (size_t)n * C + c0, a);
+    }
+}
+
+// ---- SE excitation (att.py:96-103): gate = out_act(W2 . mid_act(W1 . mean + b1) + b2), one block per image -------
+__global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                       int M, int mid_act, int out_act) {
+    extern __shared__ float sm[];       // [C] mean, then [M] mid
+    float* smean = sm;
+    float* smid = sm + C;
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) smean[c] = mean[(size_t)n * C + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = wave; m < M; m += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += w1[(size_t)m * C + c] * smean[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        if (lane == 0) smid[m] = apply_act(a + b1[m], mid_act);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = b2[c];
+        for (int m = 0; m < M; ++m) a += w2[(size_t)c * M + m] * smid[m];
+        gate[(size_t)n * C + c] = apply_act(a, out_act);
+    }
+}
+
+// y = post_act(x * gate[n,c] + residual)  (att.py:104, seresnet.py:69-71)
+template <int DT>
+__global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ x, const float* __restrict__ gate,
+                                                      const void* __restrict__ res, void* __restrict__ y, long total8,
+                                                      int HW, int C, int post_act) {
+    const int C8 = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % C8) * 8;
+        const long pix = i / C8;
+        const long n = pix / HW;
+        float v[8], g[8];
+        load8<DT>(x, (size_t)i * 8, v);
+        load8<PCV_F32>(gate, (size_t)n * C + c0, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g[e];
+        if (res != nullptr) {
+            float r[8];
+            load8<DT>(res, (size_t)i * 8, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (post_act != PCV_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], post_act);
+        }
+        store8<DT>(y, (size_t)i * 8, v);
+    }
+}

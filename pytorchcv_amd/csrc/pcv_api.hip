@@ -1,0 +1,624 @@
+// pcv_api.hip - host side of the C ABI declared in include/pcv_amd.h: argument checking, convolution planning
+// (K-chunk tables, group blocking, tile choice) and kernel launches. No torch, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "pcv_common.hpp"
+#include "igemm_conv.hpp"
+#include "dwconv.hpp"
+#include "aux_kernels.hpp"
+
+struct pcv_ctx {
+    int device = 0;
+    std::string err;
+    int num_cu = 256;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(pcv_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(ctx, PCV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int esize(int dt) { return dt == PCV_F32 ? 4 : 2; }
+static inline bool dtype_ok(int dt) { return dt == PCV_F32 || dt == PCV_BF16 || dt == PCV_F16; }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Convolution plan: everything that depends on the descriptor but not on the data pointers.
+// ---------------------------------------------------------------------------------------------------------
+struct ConvPlan {
+    int ES = 2, CE = 8;
+    bool pair = false;        // stem scheme: x_cpitch == 4 at 16 bit, one chunk = two pixels x 4 channels
+    int Ho = 0, Wo = 0;
+    int ngb = 1;              // group-blocks (blockIdx.y)
+    int Cg_in = 0, Cg_out = 0;
+    int cin_blk = 0, cout_blk = 0;
+    int nR = 1, nQ = 1;
+    int dy[IGEMM_MAX_TAPS], dx[IGEMM_MAX_TAPS];
+    int nchunks = 0, nk = 0, Kpad = 0;
+    int wrows = 0;
+    size_t ktab_bytes = 0, w_bytes = 0, total_bytes = 0;
+    std::vector<uint32_t> ktab;   // built only when tables == true
+    std::vector<uint32_t> ksrc;
+};
+
+static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
+    if (!dtype_ok(d.dtype) || !dtype_ok(d.out_dtype)) return "unknown dtype";
+    if (d.out_dtype != d.dtype && d.out_dtype != PCV_F32) return "out_dtype must equal dtype or be fp32";
+    if (d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.groups <= 0) return "non-positive conv dimension";
+    if (d.kh >= IGEMM_MAX_TAPS || d.kw >= IGEMM_MAX_TAPS) return "kernel size > 15 unsupported";
+    if (d.stride_h <= 0 || d.stride_w <= 0 || d.dil_h <= 0 || d.dil_w <= 0) return "non-positive stride/dilation";
+    if (d.Cin % d.groups || d.Cout % d.groups) return "channels not divisible by groups";
+    P.ES = esize(d.dtype);
+    P.CE = 16 / P.ES;
+    P.Cg_in = d.Cin / d.groups;
+    P.Cg_out = d.Cout / d.groups;
+    const int cpitch = d.x_cpitch > 0 ? d.x_cpitch : d.Cin;
+    if (cpitch < d.Cin) return "x_cpitch < Cin";
+    P.pair = (d.groups == 1 && cpitch == 4 && P.ES == 2);
+    if (!P.pair && cpitch % P.CE != 0) return "x_cpitch must be a multiple of 16 bytes (or 4 for a padded 16-bit stem)";
+
+    // group blocking: gpb whole groups per block, block-diagonal dense weights
+    int gpb = 1;
+    if (d.groups > 1) {
+        while (gpb < d.groups && ((gpb * P.Cg_out) % 8 != 0 || (gpb * P.Cg_in) % P.CE != 0 || gpb * P.Cg_out < 32)) ++gpb;
+        while (gpb < d.groups && d.groups % gpb != 0) ++gpb;
+        if (d.groups % gpb != 0 || (gpb * P.Cg_out) % 8 != 0 || (gpb * P.Cg_in) % P.CE != 0)
+            return "unsupported group shape (channels per group block not 16-byte aligned)";
+    }
+    P.ngb = d.groups / gpb;
+    P.cin_blk = gpb * P.Cg_in;
+    P.cout_blk = gpb * P.Cg_out;
+    if (d.groups == 1) P.cin_blk = d.Cin;
+    P.wrows = round_up(P.cout_blk, 32);
+
+    // taps
+    if (P.pair) {
+        if (d.stride_w % 2 != 0 || d.dil_w != 1) return "padded 4-channel stem needs even stride_w and dilation 1";
+        const int wp = d.x_wpitch > 0 ? d.x_wpitch : d.W;
+        if (wp % 2 != 0) return "padded 4-channel stem needs an even x_wpitch";
+        const int dxs = -(d.pad_l & 1);
+        P.nQ = (d.kw - dxs + 1) / 2;
+        P.nR = d.kh;
+        if (P.nQ >= IGEMM_MAX_TAPS) return "stem too wide";
+        for (int r = 0; r < P.nR; ++r) P.dy[r] = r * d.dil_h;
+        for (int q = 0; q < P.nQ; ++q) P.dx[q] = dxs + 2 * q;
+        P.nchunks = P.nR * P.nQ;
+    } else {
+        P.nR = d.kh;
+        P.nQ = d.kw;
+        for (int r = 0; r < P.nR; ++r) P.dy[r] = r * d.dil_h;
+        for (int q = 0; q < P.nQ; ++q) P.dx[q] = q * d.dil_w;
+        const int cchunks = (P.cin_blk + P.CE - 1) / P.CE;
+        if (d.groups == 1 && cchunks * P.CE > cpitch) return "x_cpitch too small for the channel chunks";
+        P.nchunks = P.nR * P.nQ * cchunks;
+    }
+    for (int i = P.nR; i < IGEMM_MAX_TAPS; ++i) P.dy[i] = 0;
+    for (int i = P.nQ; i < IGEMM_MAX_TAPS; ++i) P.dx[i] = 0;
+    P.nk = (P.nchunks + 7) / 8;
+    P.Kpad = P.nk * 8 * P.CE;
+    P.ktab_bytes = (size_t)round_up(P.nk * 8 * 8, 256);
+    P.w_bytes = (size_t)P.ngb * P.wrows * P.Kpad * P.ES;
+    P.total_bytes = P.ktab_bytes + P.w_bytes;
+    if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
+
+    P.Ho = (d.H + d.pad_t + d.pad_b - d.dil_h * (d.kh - 1) - 1) / d.stride_h + 1;
+    P.Wo = (d.W + d.pad_l + d.pad_r - d.dil_w * (d.kw - 1) - 1) / d.stride_w + 1;
+
+    if (tables) {
+        P.ktab.assign((size_t)P.nk * 8 * 2, 0);
+        P.ksrc.assign((size_t)P.Kpad, 0xFFFFFFFFu);
+        const int khkw = d.kh * d.kw;
+        (void)khkw;
+        int j = 0;
+        auto put = [&](int c0, int r, int q, int dyv, int dxv) {
+            P.ktab[2 * j] = (uint32_t)c0 | ((uint32_t)r << 16) | ((uint32_t)q << 20);
+            P.ktab[2 * j + 1] = ((uint32_t)dyv & 0xFFFFu) | (((uint32_t)dxv & 0xFFFFu) << 16);
+            ++j;
+        };
+        if (P.pair) {
+            for (int r = 0; r < P.nR; ++r)
+                for (int q = 0; q < P.nQ; ++q) {
+                    for (int e = 0; e < 8; ++e) {
+                        const int pix = e >> 2, c = e & 3;
+                        const int tap = P.dx[q] + pix;
+                        if (tap >= 0 && tap < d.kw && c < d.Cin)
+                            P.ksrc[(size_t)j * 8 + e] = (uint32_t)c | ((uint32_t)(r * d.kw + tap) << 16);
+                    }
+                    put(0, r, q, P.dy[r], P.dx[q]);
+                }
+        } else {
+            const int cchunks = (P.cin_blk + P.CE - 1) / P.CE;
+            for (int r = 0; r < P.nR; ++r)
+                for (int q = 0; q < P.nQ; ++q)
+                    for (int cc = 0; cc < cchunks; ++cc) {
+                        for (int e = 0; e < P.CE; ++e) {
+                            const int c = cc * P.CE + e;
+                            if (c < P.cin_blk)
+                                P.ksrc[(size_t)j * P.CE + e] = (uint32_t)c | ((uint32_t)(r * d.kw + q) << 16);
+                        }
+                        put(cc * P.CE, r, q, P.dy[r], P.dx[q]);
+                    }
+        }
+        while (j < P.nk * 8) put(0, 15, 0, 0, 0);      // r = 15 is never valid: zero-filled chunk
+    }
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel table
+// ---------------------------------------------------------------------------------------------------------
+enum TileCfg { TILE_C32 = 0, TILE_C64 = 1, TILE_C128 = 2, TILE_C256 = 3, TILE_COUNT = 4 };
+struct TileInfo { int BM, BP, threads, lds; };
+static const TileInfo kTiles[TILE_COUNT] = {
+    {32, 256, 256, 2 * (32 + 256) * 128},
+    {64, 256, 256, 2 * (64 + 256) * 128},
+    {128, 128, 256, 2 * (128 + 128) * 128},
+    {256, 64, 256, 2 * (256 + 64) * 128},
+};
+typedef void (*igemm_fn)(const IgemmParams);
+
+template <int DT, int OT, bool RG> static igemm_fn igemm_for_tile(int tile) {
+    switch (tile) {
+        case TILE_C32: return igemm_conv_kernel<DT, OT, 2, 4, 1, 4, RG>;
+        case TILE_C64: return igemm_conv_kernel<DT, OT, 4, 4, 1, 4, RG>;
+        case TILE_C128: return igemm_conv_kernel<DT, OT, 4, 4, 2, 2, RG>;
+        default: return igemm_conv_kernel<DT, OT, 4, 4, 4, 1, RG>;
+    }
+}
+// Non-ragged kernels store in the activation dtype; the ragged / fp32-output variants exist only on the 128x128 tile
+// (classifier logits, odd channel counts).
+static igemm_fn pick_igemm(int dt, int ot, bool ragged, int tile) {
+    if (!ragged && ot == dt) {
+        if (dt == PCV_BF16) return igemm_for_tile<PCV_BF16, PCV_BF16, false>(tile);
+        if (dt == PCV_F16) return igemm_for_tile<PCV_F16, PCV_F16, false>(tile);
+        return igemm_for_tile<PCV_F32, PCV_F32, false>(tile);
+    }
+    if (tile != TILE_C128) return nullptr;
+    if (ot == PCV_F32) {
+        if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_F32, 4, 4, 2, 2, true>;
+        if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F32, 4, 4, 2, 2, true>;
+        return igemm_conv_kernel<PCV_F32, PCV_F32, 4, 4, 2, 2, true>;
+    }
+    if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_BF16, 4, 4, 2, 2, true>;
+    if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F16, 4, 4, 2, 2, true>;
+    return nullptr;
+}
+
+static int enable_big_lds(pcv_ctx* ctx) {
+    for (int dt = 0; dt < 3; ++dt)
+        for (int tile = 0; tile < TILE_COUNT; ++tile)
+            for (int variant = 0; variant < 3; ++variant) {
+                igemm_fn f = variant == 0 ? pick_igemm(dt, dt, false, tile)
+                           : variant == 1 ? pick_igemm(dt, PCV_F32, true, tile)
+                                          : pick_igemm(dt, dt, true, tile);
+                if (f == nullptr) continue;
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(f),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[tile].lds));
+            }
+    return PCV_OK;
+}
+
+// launch helpers (templates need C++ linkage)
+template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
+    if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1><<<grid, 256, 0, s>>>(p);
+    else if (d.kh == 3) dwconv_kernel<DT, 3, 2><<<grid, 256, 0, s>>>(p);
+    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1><<<grid, 256, 0, s>>>(p);
+    else dwconv_kernel<DT, 5, 2><<<grid, 256, 0, s>>>(p);
+}
+
+template <int DT> static void launch_mean(const void* x, void* y, int N, int HW, int C, int ot, hipStream_t s) {
+    dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
+    if (ot == PCV_F32) spatial_mean_kernel<DT, PCV_F32><<<grid, 256, 0, s>>>(x, y, HW, C);
+    else spatial_mean_kernel<DT, DT><<<grid, 256, 0, s>>>(x, y, HW, C);
+}
+template <int DT> static void launch_avg(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int s,
+                                         int ot, hipStream_t st) {
+    const long total = (long)N * Ho * Wo * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (ot == PCV_F32) avgpool_kernel<DT, PCV_F32><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, s);
+    else avgpool_kernel<DT, DT><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, s);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int pcv_abi_version(void) { return PCV_ABI_VERSION; }
+
+const char* pcv_last_error(const pcv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int pcv_create(pcv_ctx** out, int device) {
+    if (out == nullptr) return fail(nullptr, PCV_ERR_INVALID, "pcv_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(nullptr, PCV_ERR_NO_DEVICE, "pcv_create: no HIP device visible");
+    if (device < 0 || device >= count) return fail(nullptr, PCV_ERR_INVALID, "pcv_create: bad device index");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, PCV_ERR_NO_DEVICE,
+                    std::string("pcv_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    int prev = 0;
+    HIP_TRY(nullptr, hipGetDevice(&prev));
+    HIP_TRY(nullptr, hipSetDevice(device));
+    pcv_ctx* ctx = new (std::nothrow) pcv_ctx();
+    if (ctx == nullptr) return fail(nullptr, PCV_ERR_INVALID, "pcv_create: out of host memory");
+    ctx->device = device;
+    ctx->num_cu = prop.multiProcessorCount;
+    int rc = enable_big_lds(ctx);
+    if (rc != PCV_OK) {
+        g_create_err = ctx->err;
+        delete ctx;
+        (void)hipSetDevice(prev);
+        return rc;
+    }
+    (void)hipSetDevice(prev);
+    *out = ctx;
+    return PCV_OK;
+}
+
+int pcv_destroy(pcv_ctx* ctx) {
+    delete ctx;
+    return PCV_OK;
+}
+
+// ---- layout ------------------------------------------------------------------------------------------------
+int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H, int W, int cpitch, int wpitch,
+                     int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpitch < C || wpitch < W || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_nchw_to_nhwc: bad argument");
+    if (!(cpitch == 4 || cpitch % 8 == 0) && !(dtype == PCV_F32 && cpitch % 4 == 0))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_nchw_to_nhwc: cpitch must be 4 or a multiple of 8");
+    const long npix = (long)N * H * wpitch;
+    dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cpitch + 7) / 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PCV_BF16) nchw_to_nhwc_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
+    else if (dtype == PCV_F16) nchw_to_nhwc_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
+    else nchw_to_nhwc_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_nhwc_to_nchw: bad argument");
+    const long total = (long)N * C * H * W;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == PCV_BF16) nhwc_to_nchw_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
+    else if (dtype == PCV_F16) nhwc_to_nchw_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
+    else nhwc_to_nchw_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+// ---- weights -----------------------------------------------------------------------------------------------
+int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes) {
+    if (!d || !bytes) return PCV_ERR_INVALID;
+    ConvPlan P;
+    if (plan_conv(*d, P, false) != nullptr) return PCV_ERR_INVALID;
+    *bytes = P.total_bytes;
+    return PCV_OK;
+}
+
+int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!d || !w || !packed) return fail(ctx, PCV_ERR_INVALID, "pcv_conv_pack: NULL argument");
+    if (!aligned16(packed)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv_pack: packed buffer must be 16-byte aligned");
+    ConvPlan P;
+    const char* why = plan_conv(*d, P, true);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv_pack: ") + why);
+    hipStream_t s = (hipStream_t)stream;
+    // load-time only: synchronous uploads of the two small host-built tables
+    uint32_t* ksrc_dev = nullptr;
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ksrc_dev), P.ksrc.size() * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(ksrc_dev, P.ksrc.data(), P.ksrc.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(packed, P.ktab.data(), P.ktab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(ksrc_dev);
+        return fail(ctx, PCV_ERR_HIP, std::string("pcv_conv_pack: table upload: ") + hipGetErrorString(e));
+    }
+    PackParams pp;
+    pp.w = w;
+    pp.out = static_cast<char*>(packed) + P.ktab_bytes;
+    pp.ksrc = ksrc_dev;
+    pp.ngb = P.ngb;
+    pp.wrows = P.wrows;
+    pp.Kpad = P.Kpad;
+    pp.cout_blk = P.cout_blk;
+    pp.cin_blk = d->groups == 1 ? 0 : P.cin_blk;
+    pp.Cg_in = P.Cg_in;
+    pp.Cg_out = P.Cg_out;
+    pp.khkw = d->kh * d->kw;
+    const long total = (long)P.ngb * P.wrows * P.Kpad;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (d->dtype == PCV_BF16) pack_conv_kernel<PCV_BF16><<<grid, 256, 0, s>>>(pp);
+    else if (d->dtype == PCV_F16) pack_conv_kernel<PCV_F16><<<grid, 256, 0, s>>>(pp);
+    else pack_conv_kernel<PCV_F32><<<grid, 256, 0, s>>>(pp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(ksrc_dev);
+    if (e != hipSuccess) return fail(ctx, PCV_ERR_HIP, std::string("pcv_conv_pack: ") + hipGetErrorString(e));
+    return PCV_OK;
+}
+
+static const char* check_dw(const pcv_conv_desc& d) {
+    if (!dtype_ok(d.dtype) || d.out_dtype != d.dtype) return "depthwise: out_dtype must equal dtype";
+    if (d.groups != d.Cin || d.Cin != d.Cout) return "depthwise: needs groups == Cin == Cout";
+    if (d.Cin % 8 != 0) return "depthwise: channels must be a multiple of 8";
+    if (d.kh != d.kw || (d.kh != 3 && d.kh != 5)) return "depthwise: only 3x3 and 5x5";
+    if (d.stride_h != d.stride_w || (d.stride_h != 1 && d.stride_h != 2)) return "depthwise: stride 1 or 2";
+    if (d.dil_h != 1 || d.dil_w != 1) return "depthwise: dilation unsupported";
+    if (d.x_cpitch > 0 && d.x_cpitch != d.Cin) return "depthwise: padded channel pitch unsupported";
+    if (d.x_wpitch > 0 && d.x_wpitch != d.W) return "depthwise: padded row pitch unsupported";
+    return nullptr;
+}
+
+int pcv_dwconv_packed_bytes(const pcv_conv_desc* d, size_t* bytes) {
+    if (!d || !bytes || check_dw(*d)) return PCV_ERR_INVALID;
+    *bytes = (size_t)d->kh * d->kw * d->Cin * esize(d->dtype);
+    return PCV_OK;
+}
+
+int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!d || !w || !packed) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv_pack: NULL argument");
+    const char* why = check_dw(*d);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_dwconv_pack: ") + why);
+    const int total = d->Cin * d->kh * d->kw;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == PCV_BF16) pack_dw_kernel<PCV_BF16><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
+    else if (d->dtype == PCV_F16) pack_dw_kernel<PCV_F16><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
+    else pack_dw_kernel<PCV_F32><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, const float* mean, const float* var,
+                float eps, const float* conv_bias, float* scale, float* shift, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (C <= 0 || !scale || !shift) return fail(ctx, PCV_ERR_INVALID, "pcv_bn_fold: bad argument");
+    const bool any = gamma || beta || mean || var;
+    const bool all = gamma && beta && mean && var;
+    if (any && !all) return fail(ctx, PCV_ERR_INVALID, "pcv_bn_fold: gamma/beta/mean/var must be all set or all NULL");
+    bn_fold_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, gamma, beta, mean, var, eps, conv_bias, scale, shift);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------------------------------------
+int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                     const float* shift, const void* residual, void* y, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
+    if (d->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: has_residual but residual is NULL");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty input");
+    if (d->groups > 1 && d->groups == d->Cin && d->Cin == d->Cout)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: depthwise convolution goes through pcv_dwconv2d_fused");
+    ConvPlan P;
+    const char* why = plan_conv(*d, P, false);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv2d_fused: ") + why);
+    if (P.Ho <= 0 || P.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty output");
+    const int cpitch = d->x_cpitch > 0 ? d->x_cpitch : d->Cin;
+    const int wpitch = d->x_wpitch > 0 ? d->x_wpitch : d->W;
+    const unsigned long long xbytes = (unsigned long long)d->N * d->H * wpitch * cpitch * P.ES;
+    const unsigned long long M64 = (unsigned long long)d->N * P.Ho * P.Wo;
+    if (xbytes >= 0x80000000ull || M64 >= 0x7FFFFFFFull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: input exceeds the 2 GiB window of one launch; split the batch");
+    if (!aligned16(x) || !aligned16(packed) || !aligned16(y) || (residual && !aligned16(residual)) ||
+        (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
+
+    const bool ragged = (d->Cout % 8 != 0) || (P.cout_blk % 8 != 0);
+    int tile;
+    if (ragged || d->out_dtype != d->dtype) tile = TILE_C128;
+    else if (P.cout_blk <= 32) tile = TILE_C32;
+    else if (P.cout_blk <= 64) tile = TILE_C64;
+    else if (P.cout_blk <= 128) tile = TILE_C128;
+    else if (P.cout_blk <= 256) tile = TILE_C256;
+    else tile = TILE_C128;
+    if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
+    igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, ragged || d->out_dtype != d->dtype, tile);
+    if (!fn) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: no kernel for this dtype combination");
+    const TileInfo& T = kTiles[tile];
+
+    IgemmParams p;
+    p.x = x;
+    p.ktab = reinterpret_cast<const uint32_t*>(packed);
+    p.w = static_cast<const char*>(packed) + P.ktab_bytes;
+    p.res = d->has_residual ? residual : nullptr;
+    p.y = y;
+    p.scale = scale;
+    p.shift = shift;
+    p.x_bytes = (uint32_t)xbytes;
+    p.w_bytes = (uint32_t)P.w_bytes;
+    p.M = (int)M64;
+    p.Cout = P.cout_blk;
+    p.Cout_total = d->Cout;
+    p.cout_blk = P.cout_blk;
+    p.cin_blk = d->groups == 1 ? 0 : P.cin_blk;
+    p.wrows_blk = P.wrows;
+    p.HoWo = P.Ho * P.Wo;
+    p.Wo = P.Wo;
+    p.div_howo = make_fastdiv((uint32_t)p.HoWo);
+    p.div_wo = make_fastdiv((uint32_t)p.Wo);
+    p.H = d->H;
+    p.W = d->W;
+    p.Wpitch = wpitch;
+    p.Cpitch = cpitch;
+    p.sh = d->stride_h;
+    p.sw = d->stride_w;
+    p.pt = d->pad_t;
+    p.pl = d->pad_l;
+    p.nR = P.nR;
+    p.nQ = P.nQ;
+    for (int i = 0; i < IGEMM_MAX_TAPS; ++i) { p.dy[i] = P.dy[i]; p.dx[i] = P.dx[i]; }
+    p.nk = P.nk;
+    p.Kpad = P.Kpad;
+    p.act = d->act;
+    p.post_act = d->post_act;
+    p.nPixTiles = (p.M + T.BP - 1) / T.BP;
+    p.nChTiles = (P.cout_blk + T.BM - 1) / T.BM;
+    dim3 grid((unsigned)(p.nPixTiles * p.nChTiles), (unsigned)P.ngb);
+    hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, (hipStream_t)stream, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                       const float* shift, const void* residual, void* y, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!d || !x || !packed || !y || !scale || !shift) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: NULL argument");
+    const char* why = check_dw(*d);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_dwconv2d_fused: ") + why);
+    if (d->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: has_residual but residual is NULL");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: empty input");
+    if (!aligned16(x) || !aligned16(packed) || !aligned16(y) || !aligned16(scale) || !aligned16(shift) ||
+        (residual && !aligned16(residual)))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: pointers must be 16-byte aligned");
+    DwParams p;
+    p.x = x;
+    p.w = packed;
+    p.res = d->has_residual ? residual : nullptr;
+    p.y = y;
+    p.scale = scale;
+    p.shift = shift;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin;
+    p.Ho = (d->H + d->pad_t + d->pad_b - (d->kh - 1) - 1) / d->stride_h + 1;
+    p.Wo = (d->W + d->pad_l + d->pad_r - (d->kw - 1) - 1) / d->stride_w + 1;
+    if (p.Ho <= 0 || p.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: empty output");
+    p.pt = d->pad_t; p.pl = d->pad_l;
+    p.C8 = d->Cin / 8;
+    // rows per thread: whole column when that still fills the chip (>= ~16 waves per CU), else shorter strips
+    const long cols = (long)d->N * p.Wo * p.C8;
+    const long want = (long)ctx->num_cu * 64 * 16;
+    int nseg = (int)((want + cols - 1) / cols);
+    if (nseg < 1) nseg = 1;
+    int TH = (p.Ho + nseg - 1) / nseg;
+    if (TH < 4) TH = p.Ho < 4 ? p.Ho : 4;
+    p.TH = TH;
+    p.nseg = (p.Ho + TH - 1) / TH;
+    p.act = d->act;
+    p.post_act = d->post_act;
+    p.total = cols * p.nseg;
+    const unsigned grid = (unsigned)((p.total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == PCV_BF16) launch_dw<PCV_BF16>(*d, p, grid, s);
+    else if (d->dtype == PCV_F16) launch_dw<PCV_F16>(*d, p, grid, s);
+    else launch_dw<PCV_F32>(*d, p, grid, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p, int dtype,
+                  void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || p < 0 || !dtype_ok(dtype) || C % 8 != 0 ||
+        2 * p > k)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_maxpool2d: bad argument (C must be a multiple of 8, pad <= k/2)");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    if (Ho <= 0 || Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_maxpool2d: empty output");
+    const long total = (long)N * Ho * Wo * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) maxpool_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, s, p);
+    else if (dtype == PCV_F16) maxpool_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, s, p);
+    else maxpool_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, k, s, p);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int dtype,
+                  int out_dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || !dtype_ok(dtype) || C % 8 != 0 ||
+        (out_dtype != dtype && out_dtype != PCV_F32) || k > H || k > W)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_avgpool2d: bad argument (C must be a multiple of 8, k <= H,W)");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = (H - k) / s + 1, Wo = (W - k) / s + 1;
+    if (k == H && k == W) {
+        if (dtype == PCV_BF16) launch_mean<PCV_BF16>(x, y, N, H * W, C, out_dtype, st);
+        else if (dtype == PCV_F16) launch_mean<PCV_F16>(x, y, N, H * W, C, out_dtype, st);
+        else launch_mean<PCV_F32>(x, y, N, H * W, C, out_dtype, st);
+    } else {
+        if (dtype == PCV_BF16) launch_avg<PCV_BF16>(x, y, N, H, W, C, Ho, Wo, k, s, out_dtype, st);
+        else if (dtype == PCV_F16) launch_avg<PCV_F16>(x, y, N, H, W, C, Ho, Wo, k, s, out_dtype, st);
+        else launch_avg<PCV_F32>(x, y, N, H, W, C, Ho, Wo, k, s, out_dtype, st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* bias, void* y, int N, int Cin,
+                  int Cout, int dtype, int out_dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    pcv_conv_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.N = N; d.H = 1; d.W = 1; d.Cin = Cin; d.Cout = Cout; d.kh = 1; d.kw = 1;
+    d.stride_h = d.stride_w = 1; d.dil_h = d.dil_w = 1; d.groups = 1;
+    d.act = PCV_ACT_NONE; d.post_act = PCV_ACT_NONE; d.has_residual = 0;
+    d.dtype = dtype; d.out_dtype = out_dtype; d.x_cpitch = Cin; d.x_wpitch = 1;
+    return pcv_conv2d_fused(ctx, &d, x, packed, nullptr, bias, nullptr, y, stream);
+}
+
+int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int C, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !mean || N <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_se_squeeze: bad argument (C must be a multiple of 8)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) launch_mean<PCV_BF16>(x, mean, N, HW, C, PCV_F32, st);
+    else if (dtype == PCV_F16) launch_mean<PCV_F16>(x, mean, N, HW, C, PCV_F32, st);
+    else launch_mean<PCV_F32>(x, mean, N, HW, C, PCV_F32, st);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
+                  float* gate, int N, int C, int M, int mid_act, int out_act, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!mean || !w1 || !b1 || !w2 || !b2 || !gate || N <= 0 || C <= 0 || M <= 0)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: bad argument");
+    const size_t lds = (size_t)(C + M) * sizeof(float);
+    if (lds > 64 * 1024) return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: C + M too large");
+    se_excite_kernel<<<N, 256, lds, (hipStream_t)stream>>>(mean, w1, b1, w2, b2, gate, C, M, mid_act, out_act);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y, int N, int HW, int C,
+                 int post_act, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!x || !gate || !y || N <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_se_scale: bad argument (C must be a multiple of 8)");
+    const long total8 = (long)N * HW * (C / 8);
+    long blocks = (total8 + 255) / 256;
+    const long cap = (long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
+    else if (dtype == PCV_F16) se_scale_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
+    else se_scale_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+}  // extern "C"

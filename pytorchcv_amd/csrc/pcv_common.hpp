@@ -1,0 +1,104 @@
+// pcv_common.hpp - shared device helpers for the gfx950 kernels (element types, activations, fast division).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pcv_amd.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define PCV_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- element traits: storage type tag -> bytes, conversions -------------------------------------------
+template <int DT> struct Elem;
+template <> struct Elem<PCV_F32> { static constexpr int BYTES = 4; };
+template <> struct Elem<PCV_BF16> { static constexpr int BYTES = 2; };
+template <> struct Elem<PCV_F16> { static constexpr int BYTES = 2; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __uint_as_float(b16 << 16); }
+
+// fp32 -> bf16 (round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 and keeps NaN a NaN)
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    bf2 r = __builtin_convertvector(v, bf2);
+    return *reinterpret_cast<uint32_t*>(&r);
+}
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    h2 r = __builtin_convertvector(v, h2);
+    return *reinterpret_cast<uint32_t*>(&r);
+}
+template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    if constexpr (DT == PCV_BF16) return pack2_bf16(lo, hi);
+    else return pack2_f16(lo, hi);
+}
+// unpack the two 16-bit elements of a dword
+template <int DT> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+    if constexpr (DT == PCV_BF16) {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xFFFF0000u);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        h2 v = *reinterpret_cast<h2*>(&w);
+        lo = (float)v[0];
+        hi = (float)v[1];
+    }
+}
+template <int DT> __device__ __forceinline__ float load_elem(const void* base, size_t idx) {
+    if constexpr (DT == PCV_F32) return reinterpret_cast<const float*>(base)[idx];
+    else if constexpr (DT == PCV_BF16) return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(base)[idx]);
+    else return (float)reinterpret_cast<const _Float16*>(base)[idx];
+}
+template <int DT> __device__ __forceinline__ void store_elem(void* base, size_t idx, float v) {
+    if constexpr (DT == PCV_F32) reinterpret_cast<float*>(base)[idx] = v;
+    else if constexpr (DT == PCV_BF16) reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)(pack2_bf16(v, 0.f) & 0xFFFFu);
+    else reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
+}
+
+// ---- activations (reference: pytorchcv/models/common/activ.py) ------------------------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case PCV_ACT_RELU: return fmaxf(v, 0.f);                                   // activ.py:64
+        case PCV_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);                      // activ.py:81
+        case PCV_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));                     // activ.py:132
+        case PCV_ACT_SWISH: return v / (1.f + __expf(-v));                         // activ.py:20-21
+        case PCV_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);      // activ.py:29-30
+        case PCV_ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);    // activ.py:46-47
+        default: return v;
+    }
+}
+
+// ---- exact unsigned division by a launch-time constant, n < 2^31 ----------------------------------------
+struct FastDiv {
+    uint32_t d, magic, shift;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+    uint32_t sh = 0;
+    while ((1ull << (sh + 1)) < d) ++sh;          // 2^sh < d <= 2^(sh+1)
+    f.shift = sh;
+    f.magic = (uint32_t)(((1ull << (32 + sh)) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv& f) {
+    return f.d <= 1 ? n : (__umulhi(n, f.magic) >> f.shift);
+}
+
+// XCD-aware logical tile id: blocks b and b+8 share an XCD (observed round-robin dispatch), so give each XCD a
+// contiguous run of logical tiles. Bijective for any tile count (cdna_hip_programming.md section 5, T1).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nwg) {
+    const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
+    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}

@@ -1,0 +1,305 @@
+"""
+    Host-side plumbing between the pytorchcv-style module tree and the HIP kernels: NHWC activation handles, weight
+    pre-packing (BN folding, K-major MFMA-ordered weights) cached per module, and one function per C-ABI hot-path call.
+    PyTorch is used for device memory and streams only.
+"""
+
+__all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'from_nchw', 'to_nchw', 'ConvRunner',
+           'maxpool2d', 'avgpool2d', 'se_forward', 'act_code', 'boundary']
+
+import os
+import ctypes
+import torch
+import torch.nn as nn
+from . import _lib
+from ._lib import ConvDesc
+
+DTYPES = {"fp32": (0, torch.float32), "bf16": (1, torch.bfloat16), "fp16": (2, torch.float16)}
+_CODE_OF_TORCH = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+_NAME_OF_TORCH = {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}
+
+
+def default_dtype() -> str:
+    d = os.environ.get("PCV_AMD_DTYPE", "bf16")
+    if d not in DTYPES:
+        raise ValueError("PCV_AMD_DTYPE must be one of {}".format(sorted(DTYPES)))
+    return d
+
+
+def set_compute_dtype(net: nn.Module, dtype: str) -> nn.Module:
+    """Select the storage/MFMA type of the hot path for `net`: "bf16" (default), "fp16" or "fp32"."""
+    if dtype not in DTYPES:
+        raise ValueError("dtype must be one of {}".format(sorted(DTYPES)))
+    for m in net.modules():
+        m._pcv_dtype = dtype
+    return net
+
+
+def compute_dtype_of(module: nn.Module) -> str:
+    return getattr(module, "_pcv_dtype", None) or default_dtype()
+
+
+class NHWC(object):
+    """
+    An activation on the hot path: `t` is a contiguous device tensor [N, H, wpitch, cpitch]; (H, W, C) is the logical
+    extent. wpitch/cpitch differ from W/C only for the zero-padded network input (C <= 4 -> cpitch 4, W -> even).
+    """
+    __slots__ = ("t", "N", "H", "W", "C", "wpitch", "cpitch")
+
+    def __init__(self, t, N, H, W, C, wpitch=None, cpitch=None):
+        self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
+        self.wpitch = W if wpitch is None else wpitch
+        self.cpitch = C if cpitch is None else cpitch
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def dense(self) -> bool:
+        return self.wpitch == self.W and self.cpitch == self.C
+
+    def size(self, dim=None):
+        s = (self.N, self.C, self.H, self.W)        # reported NCHW-style, as callers of the reference expect
+        return s if dim is None else s[dim]
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ctx(device):
+    if device.type != "cuda":
+        raise RuntimeError("pytorchcv_amd runs on MI355X (gfx950) only: got a tensor on '{}'. Move the model and the input "
+                           "to a CUDA/HIP device; there is no CPU path in this package.".format(device))
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _lib.ctx_for(idx)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def from_nchw(x: torch.Tensor, dtype: str, stem: bool = True) -> NHWC:
+    """fp32 NCHW -> NHWC handle (pcv_nchw_to_nhwc). With `stem`, C <= 4 is padded to 4 channels and W to even."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor")
+    x = x.contiguous().float()
+    N, C, H, W = x.shape
+    code, tdt = DTYPES[dtype]
+    if C <= 4 and stem:
+        cp, wp = 4, (W + 1) // 2 * 2
+    else:
+        cp, wp = (C + 7) // 8 * 8, W
+    y = torch.empty((N, H, wp, cp), dtype=tdt, device=x.device)
+    ctx = _ctx(x.device)
+    _lib.check(_lib.lib().pcv_nchw_to_nhwc(ctx, _ptr(x), _ptr(y), N, C, H, W, cp, wp, code, _stream(x.device)), ctx)
+    return NHWC(y, N, H, W, C, wpitch=wp, cpitch=cp)
+
+
+def to_nchw(a: NHWC) -> torch.Tensor:
+    """NHWC handle -> fp32 NCHW tensor (pcv_nhwc_to_nchw)."""
+    if not a.dense:
+        raise RuntimeError("cannot convert a padded input handle back to NCHW")
+    y = torch.empty((a.N, a.C, a.H, a.W), dtype=torch.float32, device=a.device)
+    ctx = _ctx(a.device)
+    _lib.check(_lib.lib().pcv_nhwc_to_nchw(ctx, _ptr(a.t), _ptr(y), a.N, a.C, a.H, a.W, _CODE_OF_TORCH[a.dtype],
+                                           _stream(a.device)), ctx)
+    return y
+
+
+def boundary(module: nn.Module, x, fn, stem: bool = False):
+    """Run `fn` on the hot path. An `NHWC` handle passes straight through; an NCHW fp32 tensor (how the reference's
+    blocks are called) is converted in and the result converted back, so a block is a drop-in on its own."""
+    if isinstance(x, NHWC):
+        return fn(x)
+    if not torch.is_tensor(x):
+        raise TypeError("expected a torch.Tensor or an NHWC handle")
+    y = fn(from_nchw(x, compute_dtype_of(module), stem=stem))
+    return to_nchw(y) if isinstance(y, NHWC) else y
+
+
+def act_code(activ) -> int:
+    """pcv_act code of an activation module of common/activ.py (None -> 0)."""
+    from .models.common.activ import Swish, HSigmoid, HSwish
+    if activ is None:
+        return 0
+    if isinstance(activ, nn.ReLU):
+        return 1
+    if isinstance(activ, nn.ReLU6):
+        return 2
+    if isinstance(activ, nn.Sigmoid):
+        return 3
+    if isinstance(activ, Swish):
+        return 4
+    if isinstance(activ, HSigmoid):
+        return 5
+    if isinstance(activ, HSwish):
+        return 6
+    raise NotImplementedError("activation {} has no fused MI355X epilogue yet".format(type(activ).__name__))
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+class ConvRunner(object):
+    """
+    Packed state of one Conv2d (+ optional BatchNorm2d) for one (device, dtype, input channel pitch): weights in the
+    kernel's layout and the folded fp32 scale/shift. Rebuilt whenever a source parameter changes (load_state_dict, .to()).
+    """
+    def __init__(self, conv: nn.Conv2d, bn, pad4=None):
+        self.conv, self.bn, self.pad4 = conv, bn, pad4
+        self._key = None
+        self.packed = self.scale = self.shift = None
+        self.depthwise = (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels)
+
+    def _sources(self):
+        ts = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return ts
+
+    def _state_key(self, dtype, cpitch):
+        return (dtype, cpitch) + tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
+
+    def desc(self, x: NHWC, act, post_act, has_res, out_code=None) -> ConvDesc:
+        c = self.conv
+        kh, kw = _pair(c.kernel_size)
+        sh, sw = _pair(c.stride)
+        dh, dw = _pair(c.dilation)
+        if self.pad4 is not None:               # ConvBlock's 4-tuple padding: (left, right, top, bottom)
+            pl, pr, pt, pb = [int(v) for v in self.pad4]
+        else:
+            ph, pw = _pair(c.padding)
+            pt = pb = ph
+            pl = pr = pw
+        code = _CODE_OF_TORCH[x.dtype]
+        d = ConvDesc(N=x.N, H=x.H, W=x.W, Cin=c.in_channels, Cout=c.out_channels, kh=kh, kw=kw, stride_h=sh, stride_w=sw,
+                     pad_t=pt, pad_l=pl, pad_b=pb, pad_r=pr, dil_h=dh, dil_w=dw, groups=c.groups, act=act, post_act=post_act,
+                     has_residual=1 if has_res else 0, dtype=code, out_dtype=code if out_code is None else out_code,
+                     x_cpitch=x.cpitch, x_wpitch=x.wpitch)
+        return d
+
+    def prepare(self, x: NHWC, d: ConvDesc):
+        if isinstance(c_mode := self.conv.padding_mode, str) and c_mode != "zeros":
+            raise NotImplementedError("padding_mode {}".format(c_mode))
+        key = self._state_key(x.dtype, x.cpitch)
+        if key == self._key:
+            return
+        dev = x.device
+        w = self.conv.weight
+        if w.device != dev:
+            raise RuntimeError("model parameters are on {} but the input is on {}".format(w.device, dev))
+        L, ctx, st = _lib.lib(), _ctx(dev), _stream(dev)
+        nbytes = ctypes.c_size_t(0)
+        fn_bytes = L.pcv_dwconv_packed_bytes if self.depthwise else L.pcv_conv_packed_bytes
+        if fn_bytes(ctypes.byref(d), ctypes.byref(nbytes)) != 0:
+            raise _lib.PcvError(-1, "unsupported convolution configuration: {}".format(
+                {f[0]: getattr(d, f[0]) for f in d._fields_}))
+        packed = torch.empty((nbytes.value + 15) // 16 * 16, dtype=torch.uint8, device=dev)
+        w32 = w.detach().float().contiguous()
+        fn_pack = L.pcv_dwconv_pack if self.depthwise else L.pcv_conv_pack
+        _lib.check(fn_pack(ctx, ctypes.byref(d), _ptr(w32), _ptr(packed), st), ctx)
+        C = self.conv.out_channels
+        scale = torch.empty(C, dtype=torch.float32, device=dev)
+        shift = torch.empty(C, dtype=torch.float32, device=dev)
+        bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+        if self.bn is not None:
+            if not isinstance(self.bn, nn.BatchNorm2d):
+                raise NotImplementedError("only BatchNorm2d folds into the conv epilogue, got {}".format(type(self.bn).__name__))
+            g = self.bn.weight.detach().float().contiguous() if self.bn.weight is not None else torch.ones(C, device=dev)
+            b = self.bn.bias.detach().float().contiguous() if self.bn.bias is not None else torch.zeros(C, device=dev)
+            m = self.bn.running_mean.detach().float().contiguous()
+            v = self.bn.running_var.detach().float().contiguous()
+            _lib.check(L.pcv_bn_fold(ctx, C, _ptr(g), _ptr(b), _ptr(m), _ptr(v), ctypes.c_float(self.bn.eps), _ptr(bias),
+                                     _ptr(scale), _ptr(shift), st), ctx)
+        else:
+            _lib.check(L.pcv_bn_fold(ctx, C, None, None, None, None, ctypes.c_float(0.0), _ptr(bias), _ptr(scale),
+                                     _ptr(shift), st), ctx)
+        torch.cuda.current_stream(dev).synchronize()      # w32 & friends are temporaries; load-time only
+        self.packed, self.scale, self.shift, self._key = packed, scale, shift, key
+
+    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False) -> NHWC:
+        if self.bn is not None and self.bn.training:
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None)
+        self.prepare(x, d)
+        return self._launch(x, d, residual)
+
+    def _launch(self, x: NHWC, d: ConvDesc, residual):
+        c = self.conv
+        kh, kw = d.kh, d.kw
+        Ho = (x.H + d.pad_t + d.pad_b - d.dil_h * (kh - 1) - 1) // d.stride_h + 1
+        Wo = (x.W + d.pad_l + d.pad_r - d.dil_w * (kw - 1) - 1) // d.stride_w + 1
+        if Ho <= 0 or Wo <= 0:
+            raise RuntimeError("convolution output would be empty")
+        out_dt = torch.float32 if d.out_dtype == 0 else x.dtype
+        y = torch.empty((x.N, Ho, Wo, c.out_channels), dtype=out_dt, device=x.device)
+        if residual is not None:
+            if not residual.dense or residual.t.shape != y.shape or residual.dtype != x.dtype:
+                raise RuntimeError("residual shape/dtype mismatch: {} vs {}".format(tuple(residual.t.shape), tuple(y.shape)))
+        self._launch_range(x, d, residual, y, 0, x.N)
+        return NHWC(y, x.N, Ho, Wo, c.out_channels)
+
+    def _launch_range(self, x, d, residual, y, n0, n1):
+        """Launch images [n0, n1); halve the range when one launch would exceed the 2 GiB addressing window."""
+        L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
+        d.N = n1 - n0
+        fn = L.pcv_dwconv2d_fused if self.depthwise else L.pcv_conv2d_fused
+        rc = fn(ctx, ctypes.byref(d), _ptr(x.t[n0:n1]), _ptr(self.packed), _ptr(self.scale), _ptr(self.shift),
+                _ptr(residual.t[n0:n1]) if residual is not None else None, _ptr(y[n0:n1]), st)
+        if rc == _lib.PCV_ERR_TOO_LARGE and n1 - n0 > 1:
+            mid = (n0 + n1) // 2
+            self._launch_range(x, d, residual, y, n0, mid)
+            self._launch_range(x, d, residual, y, mid, n1)
+            return
+        _lib.check(rc, ctx)
+
+
+def maxpool2d(x: NHWC, k: int, s: int, p: int) -> NHWC:
+    if not x.dense:
+        raise RuntimeError("max-pool on a padded handle")
+    Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+    y = torch.empty((x.N, Ho, Wo, x.C), dtype=x.dtype, device=x.device)
+    ctx = _ctx(x.device)
+    _lib.check(_lib.lib().pcv_maxpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, p, _CODE_OF_TORCH[x.dtype],
+                                        _stream(x.device)), ctx)
+    return NHWC(y, x.N, Ho, Wo, x.C)
+
+
+def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
+    if not x.dense:
+        raise RuntimeError("avg-pool on a padded handle")
+    if k > x.H or k > x.W:
+        raise RuntimeError("AvgPool2d kernel {} larger than the {}x{} map".format(k, x.H, x.W))
+    Ho, Wo = (x.H - k) // s + 1, (x.W - k) // s + 1
+    y = torch.empty((x.N, Ho, Wo, x.C), dtype=x.dtype, device=x.device)
+    ctx = _ctx(x.device)
+    code = _CODE_OF_TORCH[x.dtype]
+    _lib.check(_lib.lib().pcv_avgpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, code, code, _stream(x.device)), ctx)
+    return NHWC(y, x.N, Ho, Wo, x.C)
+
+
+def se_forward(x: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int, residual: NHWC | None, post_act: int) -> NHWC:
+    """SEBlock on the hot path: squeeze -> excite (fp32) -> scale (+ residual, + activation)."""
+    if not x.dense:
+        raise RuntimeError("SE on a padded handle")
+    L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
+    code = _CODE_OF_TORCH[x.dtype]
+    mean = torch.empty((x.N, x.C), dtype=torch.float32, device=x.device)
+    gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.device)
+    _lib.check(L.pcv_se_squeeze(ctx, _ptr(x.t), _ptr(mean), x.N, x.H * x.W, x.C, code, st), ctx)
+    M = w1.shape[0]
+    _lib.check(L.pcv_se_excite(ctx, _ptr(mean), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gate), x.N, x.C, M, mid_act,
+                               out_act, st), ctx)
+    y = torch.empty_like(x.t)
+    if residual is not None and (residual.t.shape != x.t.shape or residual.dtype != x.dtype):
+        raise RuntimeError("SE residual shape/dtype mismatch")
+    _lib.check(L.pcv_se_scale(ctx, _ptr(x.t), _ptr(gate), _ptr(residual.t) if residual is not None else None, _ptr(y),
+                              x.N, x.H * x.W, x.C, post_act, code, st), ctx)
+    return NHWC(y, x.N, x.H, x.W, x.C)

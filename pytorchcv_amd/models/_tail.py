@@ -1,0 +1,94 @@
+"""
+    Parameter-free pieces shared by the nets: NHWC pooling modules that stand where the reference has nn.MaxPool2d /
+    nn.AvgPool2d (same attribute names, no state), the classifier tail and the pretrained-weights hook of every factory.
+"""
+
+__all__ = ['MaxPool2dNHWC', 'AvgPool2dNHWC', 'LinearHead', 'run_net', 'maybe_load_pretrained', 'init_conv_params']
+
+import os
+import torch
+import torch.nn as nn
+from .. import engine
+
+
+class MaxPool2dNHWC(nn.Module):
+    """nn.MaxPool2d(kernel_size, stride, padding) of ResInitBlock (reference resnet.py:255-258) -> pcv_maxpool2d."""
+    def __init__(self, kernel_size, stride, padding):
+        super(MaxPool2dNHWC, self).__init__()
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+
+    def forward(self, x):
+        return engine.boundary(self, x, lambda a: engine.maxpool2d(a, self.kernel_size, self.stride, self.padding))
+
+
+class AvgPool2dNHWC(nn.Module):
+    """nn.AvgPool2d(kernel_size, stride) `final_pool` (reference resnet.py:316-318) -> pcv_avgpool2d."""
+    def __init__(self, kernel_size, stride):
+        super(AvgPool2dNHWC, self).__init__()
+        self.kernel_size, self.stride = kernel_size, stride
+
+    def forward(self, x):
+        return engine.boundary(self, x, lambda a: engine.avgpool2d(a, self.kernel_size, self.stride))
+
+
+class LinearHead(nn.Linear):
+    """nn.Linear classifier (reference resnet.py:320-322) run as the fused 1x1 GEMM with fp32 logits (pcv_gemm_bias path)."""
+    def forward(self, x):
+        if getattr(self, "_pcv_runner", None) is None:
+            conv = _LinearAsConv(self)
+            self._pcv_runner = engine.ConvRunner(conv, None)
+        if not isinstance(x, engine.NHWC):
+            raise TypeError("LinearHead expects the pooled NHWC handle")
+        if x.H != 1 or x.W != 1:
+            raise RuntimeError("classifier expects a 1x1 pooled map, got {}x{} (input size must match in_size)".format(x.H, x.W))
+        y = self._pcv_runner.run(x, out_fp32=True)
+        return y.t.view(y.N, -1)
+
+
+class _LinearAsConv(object):
+    """Duck-typed view of an nn.Linear as a 1x1 nn.Conv2d for ConvRunner (weights are shared, not copied)."""
+    def __init__(self, lin):
+        self._lin = lin
+        self.in_channels, self.out_channels = lin.in_features, lin.out_features
+        self.kernel_size, self.stride, self.padding, self.dilation, self.groups = (1, 1), (1, 1), (0, 0), (1, 1), 1
+        self.padding_mode = "zeros"
+
+    @property
+    def weight(self):
+        return self._lin.weight
+
+    @property
+    def bias(self):
+        return self._lin.bias
+
+
+def run_net(net: nn.Module, x, head):
+    """Whole-net forward: NCHW fp32 in -> NHWC hot path -> fp32 logits [N, num_classes] out."""
+    if isinstance(x, engine.NHWC):
+        return head(net.features(x))
+    if not torch.is_tensor(x) or x.dim() != 4:
+        raise TypeError("expected an NCHW tensor")
+    a = engine.from_nchw(x, engine.compute_dtype_of(net), stem=True)
+    return head(net.features(a))
+
+
+def init_conv_params(net: nn.Module):
+    """kaiming_uniform_ on every Conv2d weight, zero conv biases (what each reference net's _init_params does,
+    e.g. resnet.py:326-331)."""
+    for module in net.modules():
+        if isinstance(module, nn.Conv2d):
+            nn.init.kaiming_uniform_(module.weight)
+            if module.bias is not None:
+                nn.init.constant_(module.bias, 0)
+
+
+def maybe_load_pretrained(net, model_name, pretrained, root):
+    if pretrained:
+        if (model_name is None) or (not model_name):
+            raise ValueError("Parameter `model_name` should be properly initialized for loading pretrained model.")
+        from .common.model_store import download_model
+        download_model(net=net, model_name=model_name, local_model_store_dir_path=root)
+    return net
+
+
+DEFAULT_ROOT = os.path.join("~", ".torch", "models")

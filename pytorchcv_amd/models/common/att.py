@@ -1,0 +1,51 @@
+"""
+    Squeeze-and-Excitation (reference pytorchcv/models/common/att.py:15-105): same attributes (`conv1`/`conv2` with bias, or
+    `fc1`/`fc2`), three small launches on the hot path: spatial mean -> fp32 excitation MLP -> channel scale fused with the
+    unit's residual add and activation.
+"""
+
+__all__ = ['round_channels', 'SEBlock']
+
+import torch.nn as nn
+from .activ import lambda_relu, lambda_sigmoid, create_activation_layer
+from .conv import conv1x1
+from ... import engine
+
+
+def round_channels(channels, divisor=8):
+    """Make-divisible rule of reference att.py:15-35."""
+    rounded = max(int(channels + divisor / 2.0) // divisor * divisor, divisor)
+    if float(rounded) < 0.9 * channels:
+        rounded += divisor
+    return rounded
+
+
+class SEBlock(nn.Module):
+    def __init__(self, channels, reduction=16, mid_channels=None, round_mid=False, use_conv=True,
+                 mid_activation=lambda_relu(), out_activation=lambda_sigmoid()):
+        super(SEBlock, self).__init__()
+        self.use_conv = use_conv
+        if mid_channels is None:
+            mid_channels = channels // reduction if not round_mid else round_channels(float(channels) / reduction)
+        self.pool = nn.AdaptiveAvgPool2d(output_size=1)      # marker only; the squeeze kernel computes it
+        if use_conv:
+            self.conv1 = conv1x1(in_channels=channels, out_channels=mid_channels, bias=True)
+        else:
+            self.fc1 = nn.Linear(in_features=channels, out_features=mid_channels)
+        self.activ = create_activation_layer(mid_activation)
+        if use_conv:
+            self.conv2 = conv1x1(in_channels=mid_channels, out_channels=channels, bias=True)
+        else:
+            self.fc2 = nn.Linear(in_features=mid_channels, out_features=channels)
+        self.sigmoid = create_activation_layer(out_activation)
+
+    def _mlp(self):
+        a, b = (self.conv1, self.conv2) if self.use_conv else (self.fc1, self.fc2)
+        w1 = a.weight.detach().float().reshape(a.weight.shape[0], -1).contiguous()
+        w2 = b.weight.detach().float().reshape(b.weight.shape[0], -1).contiguous()
+        return w1, a.bias.detach().float().contiguous(), w2, b.bias.detach().float().contiguous()
+
+    def forward(self, x, residual=None, post_act=None):
+        w1, b1, w2, b2 = self._mlp()
+        return engine.boundary(self, x, lambda a: engine.se_forward(
+            a, w1, b1, w2, b2, engine.act_code(self.activ), engine.act_code(self.sigmoid), residual, engine.act_code(post_act)))

@@ -1,0 +1,123 @@
+"""
+    Convolution blocks with the reference's constructor signatures, attribute names (`conv`, `bn`, `activ` -> identical
+    state_dict keys) and factory functions (reference pytorchcv/models/common/conv.py:89-649). `forward` does not run
+    Conv2d/BatchNorm2d/activation modules: it issues ONE fused MI355X launch through the C ABI
+    (pcv_conv2d_fused / pcv_dwconv2d_fused).
+"""
+
+__all__ = ['conv1x1', 'conv3x3', 'depthwise_conv3x3', 'ConvBlock', 'conv1x1_block', 'conv3x3_block', 'conv5x5_block',
+           'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv']
+
+import torch.nn as nn
+from .activ import lambda_relu, create_activation_layer
+from .norm import lambda_batchnorm2d, create_normalization_layer
+from ... import engine
+
+
+class BareConv(nn.Conv2d):
+    """nn.Conv2d parameter holder whose forward is the fused MI355X kernel without BN/activation (reference bare
+    `conv1x1`, conv.py:89-119: SE convolutions, MobileNetV2 classifier)."""
+    def forward(self, x, out_fp32: bool = False):
+        if getattr(self, "_pcv_runner", None) is None:
+            self._pcv_runner = engine.ConvRunner(self, None)
+        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, out_fp32=out_fp32))
+
+
+def conv1x1(in_channels, out_channels, stride=1, groups=1, bias=False):
+    return BareConv(in_channels=in_channels, out_channels=out_channels, kernel_size=1, stride=stride, groups=groups, bias=bias)
+
+
+def conv3x3(in_channels, out_channels, stride=1, padding=1, dilation=1, groups=1, bias=False):
+    return BareConv(in_channels=in_channels, out_channels=out_channels, kernel_size=3, stride=stride, padding=padding,
+                    dilation=dilation, groups=groups, bias=bias)
+
+
+def depthwise_conv3x3(channels, stride=1, padding=1, dilation=1, bias=False):
+    return BareConv(in_channels=channels, out_channels=channels, kernel_size=3, stride=stride, padding=padding,
+                    dilation=dilation, groups=channels, bias=bias)
+
+
+class ConvBlock(nn.Module):
+    """
+    Convolution + BatchNorm + activation as one launch (reference ConvBlock, conv.py:204-286).
+
+    Constructor arguments are the reference's. `forward(x, residual=None, post_act=None)` additionally takes the unit's
+    skip tensor and the activation that follows the add, so `relu(body(x) + identity)` also stays in the epilogue.
+    """
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=False,
+                 normalization=lambda_batchnorm2d(), activation=lambda_relu()):
+        super(ConvBlock, self).__init__()
+        self.normalize = (normalization is not None)
+        self.activate = (activation is not None)
+        self.use_pad = (isinstance(padding, (list, tuple)) and (len(padding) == 4))
+        self._pad4 = tuple(int(p) for p in padding) if self.use_pad else None     # (left, right, top, bottom)
+        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=(0 if self.use_pad else padding), dilation=dilation, groups=groups, bias=bias)
+        if self.normalize:
+            self.bn = create_normalization_layer(normalization=normalization, num_features=out_channels)
+            if self.bn is None:
+                self.normalize = False
+            else:
+                assert isinstance(self.bn, nn.Module)
+        if self.activate:
+            self.activ = create_activation_layer(activation)
+            if self.activ is None:
+                self.activate = False
+            else:
+                assert isinstance(self.activ, nn.Module)
+        self._pcv_runner = None
+
+    def forward(self, x, residual=None, post_act=None):
+        if self._pcv_runner is None:
+            self._pcv_runner = engine.ConvRunner(self.conv, self.bn if self.normalize else None, pad4=self._pad4)
+        act = engine.act_code(self.activ) if self.activate else 0
+        pact = engine.act_code(post_act)
+        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact))
+
+
+def conv1x1_block(padding=0, **kwargs):
+    return ConvBlock(kernel_size=1, padding=padding, **kwargs)
+
+
+def conv3x3_block(padding=1, **kwargs):
+    return ConvBlock(kernel_size=3, padding=padding, **kwargs)
+
+
+def conv5x5_block(padding=2, **kwargs):
+    return ConvBlock(kernel_size=5, padding=padding, **kwargs)
+
+
+def conv7x7_block(padding=3, **kwargs):
+    return ConvBlock(kernel_size=7, padding=padding, **kwargs)
+
+
+def dwconv_block(out_channels, padding=1, **kwargs):
+    return ConvBlock(out_channels=out_channels, padding=padding, groups=out_channels, **kwargs)
+
+
+def dwconv3x3_block(padding=1, **kwargs):
+    return dwconv_block(kernel_size=3, padding=padding, **kwargs)
+
+
+def dwconv5x5_block(padding=2, **kwargs):
+    return dwconv_block(kernel_size=5, padding=padding, **kwargs)
+
+
+class DwsConvBlock(nn.Module):
+    """Depthwise-separable block = depthwise ConvBlock + pointwise ConvBlock (reference conv.py:546-618)."""
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=False,
+                 dw_normalization=lambda_batchnorm2d(), pw_normalization=lambda_batchnorm2d(), dw_activation=lambda_relu(),
+                 pw_activation=lambda_relu()):
+        super(DwsConvBlock, self).__init__()
+        self.dw_conv = dwconv_block(in_channels=in_channels, out_channels=in_channels, kernel_size=kernel_size, stride=stride,
+                                    padding=padding, dilation=dilation, bias=bias, normalization=dw_normalization,
+                                    activation=dw_activation)
+        self.pw_conv = conv1x1_block(in_channels=in_channels, out_channels=out_channels, bias=bias,
+                                     normalization=pw_normalization, activation=pw_activation)
+
+    def forward(self, x):
+        return engine.boundary(self, x, lambda a: self.pw_conv(self.dw_conv(a)))
+
+
+def dwsconv3x3_block(padding=1, **kwargs):
+    return DwsConvBlock(kernel_size=3, padding=padding, **kwargs)

@@ -1,0 +1,186 @@
+"""
+    Fixture generator - runs ONLY in the build container, where the reference (osmr/pytorchcv 0.0.73) is
+    mounted read-only at /root/reference. It imports the reference's per-model modules (the package-level
+    `pytorchcv.model_provider` needs torchvision, SURVEY.md section 8c caveat 1), loads build-generated
+    synthetic weights into them (which also proves state_dict-layout compatibility), runs the reference's
+    CPU forward and freezes inputs/outputs as small data files under tests/golden/:
+
+      manifest_<model>.json   state_dict key -> [shape, dtype], trainable parameter count
+      calib_<model>.json      per-BatchNorm (mean, var) calibration scalars used by pytorchcv_amd.synth
+      logits_<model>.npz      golden logits [4,1000] fp32, image ids, per-stage digests
+      blocks.npz/.json        ~30 single-block cases: full output tensors + manifests
+
+    Nothing of the reference is copied: fixtures are inputs/outputs only. Usage:
+        python tests/golden/make_golden.py [--ref /root/reference]
+"""
+
+import os
+import sys
+import json
+import argparse
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from pytorchcv_amd.synth import synth_state_dict, synth_input  # noqa: E402
+from cases import MODELS, BLOCK_CASES  # noqa: E402
+
+N_IMAGES = 4
+SAMPLE = 64
+
+
+def manifest_of(net):
+    sd = net.state_dict()
+    return {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
+
+
+def digest(t: torch.Tensor):
+    f = t.double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, SAMPLE).long()
+    return dict(shape=list(t.shape), sum=float(f.sum()), sumsq=float((f * f).sum()),
+                samples=[float(v) for v in t.flatten()[idx].float()])
+
+
+def calibrate(net, x):
+    """One eval-mode pass; before each BatchNorm2d runs, set its running stats from the layer's actual
+    pre-BN activations (2 scalars per layer, rounded to 6 significant digits), through the same synth rule."""
+    from pytorchcv_amd.synth import hash_normal, hash_uniform, name_stream
+    calib = {}
+    names = {m: n for n, m in net.named_modules()}
+    hooks = []
+
+    def pre_hook(mod, inp):
+        t = inp[0]
+        prefix = names[mod] + "."
+        m0 = float("{:.6g}".format(float(t.mean())))
+        v0 = float("{:.6g}".format(float(t.var(unbiased=False))))
+        calib[prefix] = [m0, v0]
+        n = mod.num_features
+        rm = m0 + 0.1 * float(np.sqrt(np.float64(v0))) * hash_normal(1234, name_stream(prefix + "running_mean"), n)
+        rv = v0 * (0.8 + 0.45 * hash_uniform(1234, name_stream(prefix + "running_var"), n))
+        mod.running_mean.copy_(torch.from_numpy(rm.astype(np.float32)))
+        mod.running_var.copy_(torch.from_numpy(rv.astype(np.float32)))
+
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            hooks.append(m.register_forward_pre_hook(pre_hook))
+    with torch.no_grad():
+        net(x)
+    for h in hooks:
+        h.remove()
+    return calib
+
+
+def pick_images(net, want=N_IMAGES, pool=128):
+    """The `want` seeded images (out of `pool`) with the largest top-1/top-2 logit margin, so that
+    "top-1 identical" is a meaningful, non-flaky check under 16-bit drift (SURVEY 7.3 iv)."""
+    margins = []
+    for b in range(0, pool, 16):
+        with torch.no_grad():
+            y = net(images(list(range(b, b + 16))))
+        top2 = torch.topk(y, 2, dim=1).values
+        margins += [float(a - c) for a, c in top2]
+    order = sorted(range(pool), key=lambda i: -margins[i])[:want]
+    return sorted(order)
+
+
+def images(ids):
+    from pytorchcv_amd.synth import hash_normal
+    return torch.stack([torch.from_numpy(hash_normal(0, 0x1A9E0000 + i, 3 * 224 * 224).astype(np.float32)).view(3, 224, 224)
+                        for i in ids])
+
+
+def make_model(ref_models, name):
+    mod = {"resnet18": "resnet", "resnet50": "resnet", "mobilenetv2_w1": "mobilenetv2",
+           "resnext101_32x4d": "resnext", "seresnet50": "seresnet"}[name]
+    m = __import__("pytorchcv.models." + mod, fromlist=[name])
+    return getattr(m, name)(pretrained=False).eval()
+
+
+def do_model(name):
+    net = make_model(None, name)
+    man = manifest_of(net)
+    from pytorchcv.models.common.model_store import calc_net_weight_count
+    nparams = int(calc_net_weight_count(net))
+    # pass 1: uncalibrated weights -> calibration scalars
+    net.load_state_dict(synth_state_dict(net.state_dict(), seed=1234), strict=True)
+    calib = calibrate(net, synth_input(2, seed=7))
+    # pass 2: the real fixture weights
+    sd = synth_state_dict(net.state_dict(), seed=1234, calib={k: tuple(v) for k, v in calib.items()})
+    net.load_state_dict(sd, strict=True)
+    ids = pick_images(net)
+    x = images(ids)
+    taps = {}
+    hooks = []
+    for cname, child in net.features.named_children():
+        if cname == "init_block" or cname.startswith("stage"):
+            hooks.append(child.register_forward_hook(lambda m, i, o, cname=cname: taps.__setitem__(cname, o.detach())))
+    with torch.no_grad():
+        y = net(x)
+    for h in hooks:
+        h.remove()
+    with open(os.path.join(HERE, "manifest_{}.json".format(name)), "w") as f:
+        json.dump(dict(model=name, param_count=nparams, keys=man), f, indent=0)
+    with open(os.path.join(HERE, "calib_{}.json".format(name)), "w") as f:
+        json.dump(calib, f, indent=0)
+    np.savez_compressed(os.path.join(HERE, "logits_{}.npz".format(name)), logits=y.numpy().astype(np.float32),
+                        image_ids=np.array(ids, dtype=np.int64))
+    with open(os.path.join(HERE, "digests_{}.json".format(name)), "w") as f:
+        json.dump({k: digest(v) for k, v in taps.items()}, f, indent=0)
+    top2 = torch.topk(y, 2, dim=1).values
+    print(name, "params", nparams, "keys", len(man), "ids", ids, "logits std %.3f absmax %.3f" % (float(y.std()), float(y.abs().max())),
+          "margins", [round(float(a - b), 3) for a, b in top2])
+
+
+def build_block(case):
+    from pytorchcv.models.common import conv as C
+    from pytorchcv.models.common.att import SEBlock
+    from pytorchcv.models.common.activ import lambda_relu6
+    from pytorchcv.models.resnet import ResUnit, ResInitBlock
+    from pytorchcv.models.mobilenetv2 import LinearBottleneck
+    from pytorchcv.models.resnext import ResNeXtUnit
+    from pytorchcv.models.seresnet import SEResUnit
+    kind, kw = case["kind"], dict(case["kwargs"])
+    if kind == "LinearBottleneck":
+        kw["activation"] = lambda_relu6()
+    ctor = {"ConvBlock": C.ConvBlock, "conv1x1_block": C.conv1x1_block, "conv3x3_block": C.conv3x3_block,
+            "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
+            "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
+            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit}[kind]
+    return ctor(**kw).eval()
+
+
+def do_blocks():
+    arrays, meta = {}, {}
+    for ci, case in enumerate(BLOCK_CASES):
+        blk = build_block(case)
+        sd = synth_state_dict(blk.state_dict(), seed=4321 + ci)
+        blk.load_state_dict(sd, strict=True)
+        x = synth_input(case["x"][0], case["x"][1], case["x"][2], case["x"][3], seed=100 + ci)
+        with torch.no_grad():
+            y = blk(x)
+        arrays[case["name"]] = y.numpy().astype(np.float32)
+        meta[case["name"]] = dict(manifest=manifest_of(blk), weight_seed=4321 + ci, input_seed=100 + ci,
+                                  y_shape=list(y.shape))
+        print(case["name"], tuple(y.shape), "absmax %.3f" % float(y.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **arrays)
+    with open(os.path.join(HERE, "blocks.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    sys.path.insert(0, args.ref)
+    torch.manual_seed(0)
+    if args.only in ("", "blocks"):
+        do_blocks()
+    for name in MODELS:
+        if args.only in ("", name):
+            do_model(name)

@@ -1,0 +1,87 @@
+"""CPU: pin the oracle (oracle/refnet.py, oracle/refblocks.py, oracle/cref.c) against the golden vectors generated from the
+imported reference (tests/golden/make_golden.py). Tolerance 1e-5 max-abs: same ATen ops, same order."""
+
+import numpy as np
+import pytest
+import torch
+import util
+from oracle import refnet, refblocks, cref
+
+TOL = 1e-5
+
+
+@pytest.mark.parametrize("case", util.BLOCK_CASES, ids=[c["name"] for c in util.BLOCK_CASES])
+def test_block_oracle_matches_reference_golden(case):
+    sd, x = util.block_state_and_input(case)
+    y = refblocks.block_forward(case["kind"], case["kwargs"], sd, x)
+    g = util.block_golden(case)
+    assert y.shape == g.shape
+    assert float((y - g).abs().max()) <= TOL * max(1.0, float(g.abs().max()))
+
+
+@pytest.mark.parametrize("name", util.MODELS)
+def test_model_oracle_matches_reference_golden(name):
+    logits, ids = util.model_golden(name)
+    sd = util.model_state(name)
+    taps = {}
+    y = refnet.forward(name, sd, util.images(ids), taps=taps)
+    assert y.shape == logits.shape == (len(ids), 1000)
+    assert float((y - logits).abs().max()) <= 2e-5
+    assert torch.equal(y.argmax(1), logits.argmax(1))
+    for stage, d in util.model_digests(name).items():
+        got = util.digest(taps[stage])
+        assert got["shape"] == d["shape"]
+        assert abs(got["sum"] - d["sum"]) <= 1e-4 * max(1.0, abs(d["sum"]))
+        assert abs(got["sumsq"] - d["sumsq"]) <= 1e-4 * max(1.0, abs(d["sumsq"]))
+        assert np.allclose(got["samples"], d["samples"], atol=2e-5)
+
+
+_SINGLE_CONV = [c for c in util.BLOCK_CASES
+                if c["kind"] in ("ConvBlock", "conv1x1_block", "conv3x3_block", "conv7x7_block", "dwconv3x3_block", "dwconv5x5_block")]
+
+
+@pytest.mark.parametrize("case", _SINGLE_CONV, ids=[c["name"] for c in _SINGLE_CONV])
+def test_plain_c_restatement_matches_golden(case):
+    """oracle/cref.c (no ATen) against the same goldens: guards the torch-based oracle against ATen-specific behaviour."""
+    sd, x = util.block_state_and_input(case)
+    kw = dict(case["kwargs"])
+    kind = case["kind"]
+    ksz = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv7x7_block": (7, 3), "dwconv3x3_block": (3, 1),
+           "dwconv5x5_block": (5, 2)}
+    pad = kw.get("padding", ksz[kind][1] if kind in ksz else 0)
+    groups = kw["out_channels"] if kind.startswith("dwconv") else kw.get("groups", 1)
+    act = kw["activation"] if "activation" in kw else "relu"
+    bn = None
+    if "bn.weight" in sd:
+        bn = (sd["bn.weight"], sd["bn.bias"], sd["bn.running_mean"], sd["bn.running_var"])
+    y = cref.conv_block_c(x.numpy(), sd["conv.weight"].numpy(), sd["conv.bias"].numpy() if "conv.bias" in sd else None,
+                          bn=[t.numpy() for t in bn] if bn else None, stride=kw.get("stride", 1), padding=pad,
+                          dilation=kw.get("dilation", 1), groups=groups, act=act)
+    g = util.block_golden(case).numpy()
+    assert y.shape == g.shape
+    assert float(np.abs(y - g).max()) <= 2e-5 * max(1.0, float(np.abs(g).max()))
+
+
+def test_plain_c_pool_linear_se():
+    x = util.synth_input(2, 16, 9, 9, seed=5)
+    assert np.allclose(cref.maxpool2d_c(x.numpy(), 3, 2, 1), torch.nn.functional.max_pool2d(x, 3, 2, 1).numpy())
+    assert np.allclose(cref.avgpool2d_c(x.numpy(), 7, 1), torch.nn.functional.avg_pool2d(x, 7, 1).numpy(), atol=1e-6)
+    w = util.synth_input(1, 1, 10, 16 * 81, seed=6).view(10, -1)
+    assert np.allclose(cref.linear_c(x.view(2, -1).numpy(), w.numpy()), (x.view(2, -1) @ w.t()).numpy(), atol=1e-4)
+    case = [c for c in util.BLOCK_CASES if c["name"] == "se_block"][0]
+    sd, xs = util.block_state_and_input(case)
+    gate = cref.se_gate_c(xs.numpy(), sd["conv1.weight"].numpy(), sd["conv1.bias"].numpy(), sd["conv2.weight"].numpy(),
+                          sd["conv2.bias"].numpy())
+    y = xs.numpy() * gate[:, :, None, None]
+    assert float(np.abs(y - util.block_golden(case).numpy()).max()) <= 1e-5
+
+
+def test_quantisation_matched_mode_is_close_to_fp32_and_idempotent():
+    case = [c for c in util.BLOCK_CASES if c["name"] == "conv3x3_s1"][0]
+    sd, x = util.block_state_and_input(case)
+    y32 = refblocks.block_forward(case["kind"], case["kwargs"], sd, x)
+    for qd, tol in (("bf16", 8e-2), ("fp16", 1e-2)):
+        yq = refblocks.block_forward(case["kind"], case["kwargs"], sd, x, quant=qd)
+        assert float((yq - y32).abs().max()) <= tol
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[qd]
+        assert torch.equal(yq, yq.to(dt).float())       # stored values are representable in the 16-bit type

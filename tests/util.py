@@ -1,0 +1,99 @@
+"""Shared helpers for the parity tests: fixture loading and block/model construction on both sides."""
+
+import os
+import json
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+from pytorchcv_amd.synth import synth_state_dict, synth_input, hash_normal  # noqa: E402
+from cases import BLOCK_CASES, MODELS  # noqa: E402,F401
+
+_blocks_npz = None
+_blocks_meta = None
+
+
+def blocks_golden():
+    global _blocks_npz, _blocks_meta
+    if _blocks_npz is None:
+        _blocks_npz = np.load(os.path.join(GOLDEN, "blocks.npz"))
+        with open(os.path.join(GOLDEN, "blocks.json")) as f:
+            _blocks_meta = json.load(f)
+    return _blocks_npz, _blocks_meta
+
+
+def template_from_manifest(manifest: dict) -> dict:
+    return {k: torch.zeros(shape, dtype=getattr(torch, dt)) for k, (shape, dt) in manifest.items()}
+
+
+def block_state_and_input(case):
+    _, meta = blocks_golden()
+    m = meta[case["name"]]
+    sd = synth_state_dict(template_from_manifest(m["manifest"]), seed=m["weight_seed"])
+    n, c, h, w = case["x"]
+    x = synth_input(n, c, h, w, seed=m["input_seed"])
+    return sd, x
+
+
+def block_golden(case) -> torch.Tensor:
+    npz, _ = blocks_golden()
+    return torch.from_numpy(npz[case["name"]])
+
+
+def build_block(case):
+    """The pytorchcv_amd counterpart of the reference block named by the case."""
+    from pytorchcv_amd.models.common import conv as C
+    from pytorchcv_amd.models.common.att import SEBlock
+    from pytorchcv_amd.models.common.activ import lambda_relu6
+    from pytorchcv_amd.models.resnet import ResUnit, ResInitBlock
+    from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
+    from pytorchcv_amd.models.resnext import ResNeXtUnit
+    from pytorchcv_amd.models.seresnet import SEResUnit
+    kind, kw = case["kind"], dict(case["kwargs"])
+    if kind == "LinearBottleneck":
+        kw["activation"] = lambda_relu6()
+    ctor = {"ConvBlock": C.ConvBlock, "conv1x1_block": C.conv1x1_block, "conv3x3_block": C.conv3x3_block,
+            "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
+            "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
+            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit}[kind]
+    return ctor(**kw).eval()
+
+
+def model_manifest(name):
+    with open(os.path.join(GOLDEN, "manifest_{}.json".format(name))) as f:
+        return json.load(f)
+
+
+def model_calib(name):
+    with open(os.path.join(GOLDEN, "calib_{}.json".format(name))) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def model_state(name, template=None):
+    if template is None:
+        template = template_from_manifest(model_manifest(name)["keys"])
+    return synth_state_dict(template, seed=1234, calib=model_calib(name))
+
+
+def model_golden(name):
+    z = np.load(os.path.join(GOLDEN, "logits_{}.npz".format(name)))
+    return torch.from_numpy(z["logits"]), [int(i) for i in z["image_ids"]]
+
+
+def model_digests(name):
+    with open(os.path.join(GOLDEN, "digests_{}.json".format(name))) as f:
+        return json.load(f)
+
+
+def images(ids):
+    return torch.stack([torch.from_numpy(hash_normal(0, 0x1A9E0000 + i, 3 * 224 * 224).astype(np.float32)).view(3, 224, 224)
+                        for i in ids])
+
+
+def digest(t: torch.Tensor, sample=64):
+    f = t.double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, sample).long()
+    return dict(shape=list(t.shape), sum=float(f.sum()), sumsq=float((f * f).sum()),
+                samples=[float(v) for v in t.flatten()[idx].float()])
