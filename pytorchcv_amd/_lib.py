@@ -55,7 +55,7 @@ _SIGS = {
 
 _lib = None
 _ctxs = {}
-_lock = threading.Lock()
+_lock = threading.RLock()
 
 
 def lib():

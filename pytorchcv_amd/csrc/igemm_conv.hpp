@@ -84,6 +84,7 @@ template <> struct Mma<PCV_F32> {
 // PB: 16-pixel blocks per wave.  WC x WP: wave grid (channels x pixels).  RAGGED: Cout not a multiple of 8.
 template <int DT, int OT, int CB, int PB, int WC, int WP, bool RAGGED>
 __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     constexpr int NW = WC * WP;
     constexpr int BM = 16 * CB * WC;          // channel rows per block tile
     constexpr int BP = 16 * PB * WP;          // pixel rows per block tile
@@ -296,4 +297,5 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }

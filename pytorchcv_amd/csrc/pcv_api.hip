@@ -6,9 +6,18 @@
 #include <cstring>
 #include <cstdio>
 #include "pcv_common.hpp"
-#include "igemm_conv.hpp"
+#include "igemm_inst.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
+
+
+IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
+IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
+IGEMM_DECLARE(PCV_F32, PCV_F32, 2, 4, 1, 4, false)
+IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 1, 4, false)
+IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 2, 2, false)
+IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 4, 1, false)
+IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 2, 2, true)
 
 struct pcv_ctx {
     int device = 0;

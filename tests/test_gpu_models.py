@@ -1,0 +1,90 @@
+"""
+GPU parity, whole nets: `get_model(name)` + the fixture weights, forward through the C ABI on MI355X, against the
+golden logits of the imported reference and the oracle.
+
+  fp32       : |logits - golden| <= 1e-3, top-1 identical                     (north-star fp32 bound)
+  bf16, fp16 : |logits - quantisation-matched oracle| <= 1e-2, top-1 identical (north-star 16-bit bound, SURVEY 7.3 ii);
+               the raw distance to the fp32 golden is printed and bounded loosely (bf16 0.5, fp16 0.08) - single-pass
+               bf16 operands cannot reach 1e-2 against an fp32 forward (SURVEY Appendix B measured 0.2).
+"""
+
+import pytest
+import torch
+import util
+from oracle import refnet
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(name, dtype, dev):
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model
+    net = get_model(name).eval()
+    net.load_state_dict(util.model_state(name, net.state_dict()), strict=True)
+    return pytorchcv_amd.set_compute_dtype(net.to(dev), dtype)
+
+
+@pytest.mark.parametrize("name", util.MODELS)
+def test_model_fp32_matches_reference_golden(name, cuda_device):
+    logits, ids = util.model_golden(name)
+    net = _net(name, "fp32", cuda_device)
+    with torch.no_grad():
+        y = net(util.images(ids).to(cuda_device))
+    torch.cuda.synchronize()
+    y = y.cpu()
+    assert y.shape == (len(ids), 1000) and y.dtype == torch.float32
+    err = float((y - logits).abs().max())
+    print("{} fp32: max|d|={:.3e}".format(name, err))
+    assert err <= 1e-3
+    assert torch.equal(y.argmax(1), logits.argmax(1))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", util.MODELS)
+def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_device):
+    logits, ids = util.model_golden(name)
+    net = _net(name, dtype, cuda_device)
+    x = util.images(ids)
+    with torch.no_grad():
+        y = net(x.to(cuda_device))
+    torch.cuda.synchronize()
+    y = y.cpu()
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = refnet.forward(name, sd, x, quant=dtype)
+    err = float((y - ref).abs().max())
+    raw = float((y - logits).abs().max())
+    print("{} {}: vs matched oracle {:.3e}; vs fp32 golden {:.3e}; top-1 vs golden equal: {}".format(
+        name, dtype, err, raw, bool(torch.equal(y.argmax(1), logits.argmax(1)))))
+    assert err <= 1e-2
+    assert torch.equal(y.argmax(1), ref.argmax(1))
+    assert raw <= (0.5 if dtype == "bf16" else 0.08)
+
+
+def test_batch_independence_and_determinism(cuda_device):
+    """Image i's logits do not depend on the rest of the batch, and a rerun is bit-identical."""
+    net = _net("resnet18", "bf16", cuda_device)
+    _, ids = util.model_golden("resnet18")
+    x = util.images(ids).to(cuda_device)
+    with torch.no_grad():
+        y = net(x)
+        y2 = net(x)
+        y_single = torch.cat([net(x[i:i + 1]) for i in range(x.shape[0])])
+    assert torch.equal(y, y2)
+    assert torch.equal(y, y_single)
+
+
+def test_odd_num_classes_and_in_channels(cuda_device):
+    """num_classes not a multiple of 8 (ragged epilogue) and a 1-channel input (padded stem)."""
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model
+    net = get_model("resnet18", num_classes=10, in_channels=1).eval()
+    sd = util.synth_state_dict(net.state_dict(), seed=99)
+    net.load_state_dict(sd)
+    net = pytorchcv_amd.set_compute_dtype(net.to(cuda_device), "fp32")
+    x = util.synth_input(2, 1, 224, 224, seed=3)
+    with torch.no_grad():
+        y = net(x.to(cuda_device)).cpu()
+    # oracle with the same state dict (architecture differs from the named model only in the stem/classifier shapes)
+    ref = refnet.resnet_forward(sd, x, blocks=18)
+    assert y.shape == (2, 10)
+    assert float((y - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
