@@ -7,7 +7,11 @@ Tolerances (written here on purpose):
   bf16 / fp16: vs the quantisation-matched oracle (same rounding points, oracle/refnet.py): |d| <= 1e-2 * max(1, |ref|)
                - one 16-bit ulp at the block's output magnitude (|y| reaches 8-10 on these fixtures, where a bf16 ulp is
                0.03-0.06, so a bare 1e-2 is below the storage precision of the output itself);
-               vs the fp32 golden: |d| <= 1e-2 + rtol * |golden| with rtol = 2^-6 (bf16) / 2^-9 (fp16).
+               vs the fp32 golden: fp16 |d| <= 1e-2 + 2^-9 |golden| (the north-star 16-bit bound holds against the raw
+               fp32 reference); bf16 |d| <= 4e-2 + 2^-7 |golden| - rounding the OPERANDS to 8 mantissa bits alone moves a
+               single ConvBlock 0.02-0.05 away from the fp32 forward (SURVEY Appendix B measured 0.049), so for bf16 the
+               1e-2 bar is the quantisation-matched one above and this line only bounds the drift. Compound units
+               (3-4 chained convolutions) get 3x both terms.
 """
 
 import pytest
@@ -55,8 +59,9 @@ def test_block_16bit_matches_oracle_and_golden(case, dtype, cuda_device):
     bound = 1e-2 * torch.clamp(ref.abs(), min=1.0)
     assert bool((d <= bound).all()), "vs quantisation-matched oracle: max |d| {:.3e} at |ref| {:.3f}".format(
         float(d.max()), float(ref.flatten()[d.argmax()].abs()))
-    rtol = (2.0 ** -6 if dtype == "bf16" else 2.0 ** -9) * (3.0 if case["kind"] in _UNITS else 1.0)
-    atol = 1e-2 * (3.0 if case["kind"] in _UNITS else 1.0)
+    mult = 3.0 if case["kind"] in _UNITS else 1.0
+    rtol = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -9) * mult
+    atol = (4e-2 if dtype == "bf16" else 1e-2) * mult
     dg = (y - g).abs()
     assert bool((dg <= atol + rtol * g.abs()).all()), "vs fp32 golden: max |d| {:.3e}".format(float(dg.max()))
 
