@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""
+bench.py - images/sec of the MI355X conv-net inference hot path (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload resnet50_bs256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the workload's batch through `get_model(name)` (fp32 NCHW input resident in HBM -> NHWC bf16 ->
+fused HIP kernels -> fp32 logits) followed, for N > 1, by the all-gather of the logits. Weak scaling: every rank runs the
+full per-GPU batch. Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (3x3 dense convolutions
+of ResNet-50: algorithmic FLOPs / HIP-event time per launch vs the 2.5 PFLOP/s dense bf16 MFMA peak; for MobileNetV2 the
+depthwise kernels vs the 8 TB/s HBM peak) and `cpu_baseline` (the oracle's torch-fp32 CPU forward on the host cores).
+"""
+
+import os
+import sys
+import json
+import time
+import argparse
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (model, per-GPU batch, kernel class for the roofline, bound)
+    "resnet50_bs256": ("resnet50", 256, "dense3x3", "mfma"),
+    "mobilenetv2_w1_bs512": ("mobilenetv2_w1", 512, "depthwise", "hbm"),
+    "resnext101_32x4d_bs256": ("resnext101_32x4d", 256, "grouped3x3", "hbm"),
+    "resnet18_bs256": ("resnet18", 256, "dense3x3", "mfma"),
+}
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def calib_for(model):
+    p = os.path.join(ROOT, "tests", "golden", "calib_{}.json".format(model))
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+class LaunchTimer(object):
+    """Brackets every ConvRunner launch of one kernel class with events on the launch stream (torch's current stream,
+    which is the stream handed to the C ABI) and accumulates algorithmic FLOPs / bytes per launch."""
+    def __init__(self, klass):
+        self.klass = klass
+        self.records = []      # (start_event, end_event, flops, bytes, tag)
+        self._orig = None
+
+    @staticmethod
+    def classify(runner, d):
+        if runner.depthwise:
+            return "depthwise"
+        if d.groups > 1:
+            return "grouped3x3" if d.kh == 3 else "grouped"
+        if d.kh == 3 and d.kw == 3 and d.x_cpitch != 4:
+            return "dense3x3"
+        if d.kh == 1 and d.kw == 1:
+            return "dense1x1"
+        return "stem"
+
+    def __enter__(self):
+        from pytorchcv_amd import engine
+        timer = self
+        self._orig = engine.ConvRunner._launch
+
+        def timed(runner, x, d, residual):
+            if timer.classify(runner, d) != timer.klass:
+                return timer._orig(runner, x, d, residual)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = timer._orig(runner, x, d, residual)
+            e.record()
+            es = x.t.element_size()
+            cin_g = d.Cin // d.groups
+            flops = 2.0 * y.N * y.H * y.W * d.Cout * cin_g * d.kh * d.kw
+            nbytes = (x.N * x.H * x.W * d.Cin + y.N * y.H * y.W * d.Cout * (2 if residual is not None else 1)) * es \
+                + d.Cout * cin_g * d.kh * d.kw * es
+            timer.records.append((s, e, flops, nbytes, "{}x{}x{}->{} k{} s{}".format(x.H, x.W, d.Cin, d.Cout, d.kh, d.stride_h)))
+            return y
+
+        engine.ConvRunner._launch = timed
+        return self
+
+    def __exit__(self, *a):
+        from pytorchcv_amd import engine
+        engine.ConvRunner._launch = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        n = len(self.records)
+        if n == 0:
+            return None
+        ms = [s.elapsed_time(e) for s, e, _, _, _ in self.records]
+        total_ms = sum(ms)
+        flops = sum(r[2] for r in self.records)
+        nbytes = sum(r[3] for r in self.records)
+        per_shape = {}
+        for (s, e, f, b, tag), t in zip(self.records, ms):
+            a = per_shape.setdefault(tag, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += t
+            a[2] += f
+            a[3] += b
+        return dict(launches=n, avg_ms=total_ms / n, tflops=flops / (total_ms * 1e-3) / 1e12,
+                    gbs=nbytes / (total_ms * 1e-3) / 1e9, flops_per_launch=flops / n, bytes_per_launch=nbytes / n,
+                    per_shape={k: dict(launches=v[0], avg_us=1e3 * v[1] / v[0], tflops=v[2] / (v[1] * 1e-3) / 1e12,
+                                       gbs=v[3] / (v[1] * 1e-3) / 1e9) for k, v in per_shape.items()})
+
+
+def cpu_baseline(model, sd_cpu, budget_s=20.0):
+    """The oracle's CPU forward (torch eager fp32 = the ATen path the reference runs), bounded sample, host cores."""
+    from oracle import refnet
+    from pytorchcv_amd.synth import synth_input
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    bs = 16
+    x = synth_input(bs, seed=11)
+    t0 = time.time()
+    refnet.forward(model, sd_cpu, x[:2])                      # warm-up (thread pool, oneDNN primitives)
+    iters, elapsed = 0, 0.0
+    t_start = time.time()
+    while iters < 1 or (time.time() - t_start < budget_s * 0.5 and iters < 8):
+        t1 = time.time()
+        refnet.forward(model, sd_cpu, x)
+        elapsed += time.time() - t1
+        iters += 1
+    return dict(value=round(bs * iters / elapsed, 2), unit="images/sec", cores=cores, kind="port",
+                sample="{} forward(s) of batch {} at 224x224, fp32, torch {} eager CPU ops via oracle/refnet.py "
+                       "({:.1f} s incl. warm-up)".format(iters, bs, torch.__version__, time.time() - t0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="resnet50_bs256", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/debug only)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus {} needs `python -m torch.distributed.run --nproc-per-node {}`".format(args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model
+    from pytorchcv_amd.synth import synth_state_dict, synth_input
+    from pytorchcv_amd.parallel import ShardedInference, broadcast_module_state
+
+    model, batch, klass, bound = WORKLOADS[args.workload]
+    if args.batch > 0:
+        batch = args.batch
+    net = get_model(model).eval()
+    sd_cpu = None
+    if rank == 0:
+        sd_cpu = synth_state_dict(net.state_dict(), seed=1234, calib=calib_for(model))
+        net.load_state_dict(sd_cpu, strict=True)
+    net = pytorchcv_amd.set_compute_dtype(net.to(dev), args.dtype)
+    if world > 1:
+        broadcast_module_state(net, src=0)           # RCCL broadcast of rank 0's weights over xGMI
+
+    # synthetic N(0,1)-like images: 8 distinct seeded images tiled to the batch (performance is data independent)
+    base = synth_input(8, seed=rank).to(dev)
+    x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+    runner = ShardedInference(net)
+
+    def step():
+        y = runner.run_local(x)
+        return runner.gather(y) if world > 1 else y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(y).all())
+
+    # per-launch HIP-event timing of the roofline kernel class (separate pass, not part of `value`)
+    roof = None
+    if rank == 0:
+        with LaunchTimer(klass) as lt:
+            for _ in range(max(3, min(args.steps, 10))):
+                runner.run_local(x)
+        s = lt.summary()
+        if s is not None:
+            if bound == "mfma":
+                roof = dict(bound="mfma", achieved=round(s["tflops"], 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(s["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=None)
+            else:
+                roof = dict(bound="hbm", achieved=round(s["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(s["gbs"] / HBM_PEAK_GBS, 4), traffic=None)
+            roof.update(kernel_class=klass, launches_per_step=s["launches"] // max(3, min(args.steps, 10)),
+                        avg_launch_us=round(1e3 * s["avg_ms"], 2),
+                        algorithmic_per_launch=(round(s["flops_per_launch"] / 1e9, 3) if bound == "mfma"
+                                                else round(s["bytes_per_launch"] / 1e6, 3)),
+                        algorithmic_unit="GFLOP" if bound == "mfma" else "MB",
+                        per_shape={k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in s["per_shape"].items()})
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model, sd_cpu)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "images/sec @224x224 ({} bs={}/GPU)".format(model, batch),
+            "value": round(world * batch * args.steps / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
+            "config": {"workload": args.workload, "model": model, "per_gpu_batch": batch, "global_batch": world * batch,
+                       "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,8 @@
 // r holds K-chunk s ^ (r & 7) (swizzle applied on the source side, LDS image stays lane-linear) so that the
 // `ds_read_b128` fragment reads of 16 consecutive rows are bank-conflict free.
 //
-// Pipeline: 2 LDS stages; per K-step one barrier: { wait DMA(t) ; barrier ; issue DMA(t+1) ; MFMA(t) }.
+// Pipeline: 2 LDS stages; per K-step one barrier: { wait DMA(t) ; barrier ; issue DMA(t+1) ; MFMA(t) }, running
+// across tile boundaries (persistent blocks).
 #pragma once
 #include "pcv_common.hpp"
 
@@ -52,6 +53,10 @@ struct IgemmParams {
     int Kpad;               // packed row length in elements
     int act, post_act;
     int nPixTiles, nChTiles;
+    int ngb;                // group-blocks (block-diagonal grouped convolution), 1 for dense
+    int nTiles;             // nPixTiles * ngb * nChTiles
+    int Cin;                // input channels per group-block (KHW == 1: chunks beyond it are zero-filled)
+    int ksteps_per_tap;     // KHW == 9: K-steps per filter tap (= cin_blk / elements per K-step)
 };
 
 template <int DT> struct Mma;
@@ -82,7 +87,14 @@ template <> struct Mma<PCV_F32> {
 
 // DT: storage type of x / w / residual.  OT: storage type of y.  CB: 16-channel blocks per wave (2 or 4).
 // PB: 16-pixel blocks per wave.  WC x WP: wave grid (channels x pixels).  RAGGED: Cout not a multiple of 8.
-template <int DT, int OT, int CB, int PB, int WC, int WP, bool RAGGED>
+// KHW: 0 = taps from the descriptor table, 1 = 1x1 without padding (every tap valid, chunk offsets computed),
+//      9 = 3x3 dilation 1 with Cin a multiple of one K-step (tap and channel offset of a K-step computed, no table).
+//
+// Persistent-capable: every block walks a strided list of tiles inside its XCD's contiguous tile range (one tile per
+// block when the host launches as many blocks as tiles). The software pipeline runs across tile boundaries: the
+// LDS-DMA loads of the next tile's first K-step are issued before this tile's last MFMAs and epilogue. The residual
+// tile and scale/shift are fetched to registers BEFORE the last K-step's MFMAs so their latency hides under them.
+template <int DT, int OT, int CB, int PB, int WC, int WP, bool RAGGED, int KHW>
 __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     constexpr int NW = WC * WP;
@@ -93,6 +105,7 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     constexpr int STAGE = (BM + BP) * 128;    // bytes per LDS stage
     constexpr int WLOADS = BM / (8 * NW);     // LDS-DMA wave-instructions per thread for the weight tile
     constexpr int XLOADS = BP / (8 * NW);
+    constexpr int NPAIR = CB / 2;
     static_assert(BM % (8 * NW) == 0 && BP % (8 * NW) == 0, "tile rows must split evenly over the waves");
     typedef typename Mma<DT>::frag frag;
 
@@ -103,98 +116,121 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wave / WP, wp = wave % WP;
 
-    // ---- which tile -------------------------------------------------------------------------------------
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int chTile = tile % p.nChTiles;
-    const int pixTile = tile / p.nChTiles;
-    const int gb = blockIdx.y;
-    const int tileP0 = pixTile * BP;
+    // ---- this block's tile list: tiles [tile, tend) of its XCD's range, stride = blocks per XCD ----------------
+    const int perXcd = (p.nTiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int tstride = gridDim.x >> 3;                      // host guarantees gridDim.x % 8 == 0
+    int tile = xcd * perXcd + (int)(blockIdx.x >> 3);
+    const int tend = min(p.nTiles, (xcd + 1) * perXcd);
+    if (tile >= tend) return;
 
-    // ---- per-thread gather state: XLOADS pixel rows, one K-chunk column --------------------------------
     const int lrow = lane >> 3;               // row within an 8-row DMA piece
     const int cs = (lane & 7) ^ lrow;         // K-chunk this lane fetches (source-side swizzle)
-    int rbase[XLOADS];
-    uint32_t rmask[XLOADS];
+    const int nR = KHW == 9 ? 3 : (KHW == 1 ? 1 : p.nR);
+    const int nQ = KHW == 9 ? 3 : (KHW == 1 ? 1 : p.nQ);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // per-tile gather state: XLOADS pixel rows + WLOADS weight rows per thread
+    struct TileState {
+        int rbase[XLOADS];
+        uint32_t rmask[XLOADS];
+        uint32_t woff[WLOADS];
+        int chTile, gb, tileP0;
+    };
+    auto setup = [&](int t, TileState& S) {
+        S.chTile = t % p.nChTiles;
+        const int t2 = t / p.nChTiles;
+        S.gb = t2 % p.ngb;
+        S.tileP0 = (t2 / p.ngb) * BP;
 #pragma unroll
-    for (int i = 0; i < XLOADS; ++i) {
-        const int prow = 8 * (i * NW + wave) + lrow;
-        const int m = tileP0 + prow;
-        uint32_t mask = 0;
-        int base = 0;
-        if (m < p.M) {
-            const uint32_t n = fastdiv((uint32_t)m, p.div_howo);
-            const uint32_t rem = (uint32_t)m - n * (uint32_t)p.HoWo;
-            const uint32_t ho = fastdiv(rem, p.div_wo);
-            const uint32_t wo = rem - ho * (uint32_t)p.Wo;
-            const int hi0 = (int)ho * p.sh - p.pt;
-            const int wi0 = (int)wo * p.sw - p.pl;
-            base = (((int)n * p.H + hi0) * p.Wpitch + wi0) * p.Cpitch + gb * p.cin_blk;
-            for (int r = 0; r < p.nR; ++r)
-                mask |= ((uint32_t)(hi0 + p.dy[r]) < (uint32_t)p.H ? 1u : 0u) << r;
-            for (int q = 0; q < p.nQ; ++q)
-                mask |= ((uint32_t)(wi0 + p.dx[q]) < (uint32_t)p.W ? 1u : 0u) << (16 + q);
+        for (int i = 0; i < XLOADS; ++i) {
+            const int m = S.tileP0 + 8 * (i * NW + wave) + lrow;
+            uint32_t mask = 0;
+            int base = 0;
+            if (m < p.M) {
+                const uint32_t n = fastdiv((uint32_t)m, p.div_howo);
+                const uint32_t rem = (uint32_t)m - n * (uint32_t)p.HoWo;
+                const uint32_t ho = fastdiv(rem, p.div_wo);
+                const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+                const int hi0 = (int)ho * p.sh - p.pt;
+                const int wi0 = (int)wo * p.sw - p.pl;
+                base = (((int)n * p.H + hi0) * p.Wpitch + wi0) * p.Cpitch + S.gb * p.cin_blk;
+                if constexpr (KHW == 1) {
+                    mask = 0x00010001u;
+                } else {
+                    for (int r = 0; r < nR; ++r)
+                        mask |= ((uint32_t)(hi0 + p.dy[r]) < (uint32_t)p.H ? 1u : 0u) << r;
+                    for (int q = 0; q < nQ; ++q)
+                        mask |= ((uint32_t)(wi0 + p.dx[q]) < (uint32_t)p.W ? 1u : 0u) << (16 + q);
+                }
+            }
+            S.rbase[i] = base;
+            S.rmask[i] = mask;
         }
-        rbase[i] = base;
-        rmask[i] = mask;
-    }
-    // weight rows: loop-invariant byte offsets, the K-step advance goes through the scalar offset
-    uint32_t woff[WLOADS];
 #pragma unroll
-    for (int i = 0; i < WLOADS; ++i) {
-        const int wrow = 8 * (i * NW + wave) + lrow;
-        woff[i] = (uint32_t)(((gb * p.wrows_blk + chTile * BM + wrow) * p.Kpad + cs * CE) * ES);
-    }
+        for (int i = 0; i < WLOADS; ++i) {
+            const int wrow = 8 * (i * NW + wave) + lrow;
+            S.woff[i] = (uint32_t)(((S.gb * p.wrows_blk + S.chTile * BM + wrow) * p.Kpad + cs * CE) * ES);
+        }
+    };
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
 
-    auto load_kdesc = [&](int t) -> u32x2 {
-        return *reinterpret_cast<const u32x2*>(p.ktab + 2 * (t * 8 + cs));
-    };
-    auto stage = [&](int t, int buf, u32x2 kd) {
+    // issue the LDS-DMA loads of K-step k of tile state S into stage `buf`
+    auto stage = [&](const TileState& S, int k, int buf) {
         char* sbase = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < WLOADS; ++i) {
             char* dst = sbase + (8 * (i * NW + wave)) * 128;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, PCV_LDS(dst), 16, woff[i], t * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, PCV_LDS(dst), 16, S.woff[i], k * 128, 0, 0);
         }
-        const int c0 = (int)(kd[0] & 0xFFFFu);
-        const uint32_t r = (kd[0] >> 16) & 15u, q = (kd[0] >> 20) & 15u;
-        const int dy = (int)(short)(kd[1] & 0xFFFFu), dx = (int)(short)(kd[1] >> 16);
-        const int koff = (dy * p.Wpitch + dx) * p.Cpitch + c0;
+        int koff;
+        uint32_t r, q;
+        bool chunk_ok = true;
+        if constexpr (KHW == 1) {
+            const int c0 = (k * 8 + cs) * CE;                  // channel chunk; beyond Cin -> zero fill
+            koff = c0;
+            r = 0; q = 0;
+            chunk_ok = c0 < p.Cin;
+        } else if constexpr (KHW == 9) {
+            const int tap = k / p.ksteps_per_tap;             // uniform: a K-step never straddles taps here
+            const int c0 = (k - tap * p.ksteps_per_tap) * (8 * CE) + cs * CE;
+            r = (uint32_t)tap / 3u;
+            q = (uint32_t)tap - 3u * r;
+            koff = ((int)r * p.Wpitch + (int)q) * p.Cpitch + c0;
+        } else {
+            const u32x2 kd = *reinterpret_cast<const u32x2*>(p.ktab + 2 * (k * 8 + cs));
+            const int c0 = (int)(kd[0] & 0xFFFFu);
+            r = (kd[0] >> 16) & 15u;
+            q = (kd[0] >> 20) & 15u;
+            const int dy = (int)(short)(kd[1] & 0xFFFFu), dx = (int)(short)(kd[1] >> 16);
+            koff = (dy * p.Wpitch + dx) * p.Cpitch + c0;
+        }
 #pragma unroll
         for (int i = 0; i < XLOADS; ++i) {
             char* dst = sbase + (BM + 8 * (i * NW + wave)) * 128;
-            const bool ok = ((rmask[i] >> r) & (rmask[i] >> (16 + q)) & 1u) != 0;
-            const uint32_t voff = ok ? (uint32_t)((rbase[i] + koff) * ES) : 0x80000000u;
+            const bool ok = chunk_ok && (((S.rmask[i] >> r) & (S.rmask[i] >> (16 + q)) & 1u) != 0);
+            const uint32_t voff = ok ? (uint32_t)((S.rbase[i] + koff) * ES) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(dst), 16, voff, 0, 0, 0);
         }
     };
 
     // ---- fragment read addresses ------------------------------------------------------------------------
-    const int fr = lane & 15, fq = lane >> 4;
     const int swz0 = ((fq) ^ (fr & 7)) << 4;
     const int swz1 = ((fq + 4) ^ (fr & 7)) << 4;
     const int wfrag = (wc * 16 * CB + fr) * 128;
     const int xfrag = (BM + wp * 16 * PB + fr) * 128;
 
     f32x4 acc[CB][PB];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < CB; ++i)
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
-        for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- main loop ----------------------------------------------------------------------------------------
-    u32x2 kd = load_kdesc(0);
-    stage(0, 0, kd);
-    if (p.nk > 1) kd = load_kdesc(1);
-    for (int t = 0; t < p.nk; ++t) {
-        __syncthreads();                       // DMA(t) landed for every wave; stage (t+1)&1 is free again
-        if (t + 1 < p.nk) {
-            stage(t + 1, (t + 1) & 1, kd);
-            if (t + 2 < p.nk) kd = load_kdesc(t + 2);
-        }
-        const char* sbase = smem + (t & 1) * STAGE;
+            for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto compute = [&](int buf) {
+        const char* sbase = smem + buf * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swz = kk == 0 ? swz0 : swz1;
@@ -208,94 +244,148 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
 #pragma unroll
                 for (int j = 0; j < PB; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
         }
-    }
+    };
 
-    // ---- epilogue: scale/shift -> act -> (+residual) -> post_act -> NHWC store ----------------------------
-    // Packed weight row (16*i + rho) of a 64-row group holds channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3),
-    // so lane group fq owns the 8 consecutive channels 32*ip + 8*fq .. +7 (accumulators 2ip and 2ip+1).
-    const int chBlk = chTile * BM + wc * 16 * CB;       // first channel (within the group-block) of this wave
-    const int chGlob0 = gb * p.cout_blk;
-#pragma unroll
-    for (int ip = 0; ip < CB / 2; ++ip) {
-        const int ch0 = chBlk + 32 * ip + 8 * fq;       // within the group-block
-        if (ch0 >= p.Cout) continue;
-        const int chg = chGlob0 + ch0;                  // global channel
-        float sc[8], sf[8];
-        if constexpr (RAGGED) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = ch0 + e < p.Cout;
-                sc[e] = ok ? (p.scale ? p.scale[chg + e] : 1.f) : 0.f;
-                sf[e] = ok ? (p.shift ? p.shift[chg + e] : 0.f) : 0.f;
-            }
-        } else {
-            f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
-            if (p.scale != nullptr) {
-                s0 = *reinterpret_cast<const f32x4*>(p.scale + chg);
-                s1 = *reinterpret_cast<const f32x4*>(p.scale + chg + 4);
-            }
-            if (p.shift != nullptr) {
-                h0 = *reinterpret_cast<const f32x4*>(p.shift + chg);
-                h1 = *reinterpret_cast<const f32x4*>(p.shift + chg + 4);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; sf[e] = h0[e]; sf[4 + e] = h1[e]; }
+    zero_acc();
+    TileState cur, nxt;
+    setup(tile, cur);
+    stage(cur, 0, 0);
+    int buf = 0;
+    const int nk = p.nk;
+
+    while (true) {
+        // ---- K-steps 0 .. nk-2: tight loop, one barrier each --------------------------------------------------
+        for (int k = 0; k + 1 < nk; ++k) {
+            __syncthreads();                   // DMA(k) landed for every wave; the other stage is free again
+            stage(cur, k + 1, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
         }
+        // ---- last K-step of the tile: prefetch next tile's first K-step + this tile's epilogue operands --------
+        const int ntile = tile + tstride;
+        const bool has_next = ntile < tend;
+        if (has_next) setup(ntile, nxt);       // address math overlaps the DMA wait
+        __syncthreads();
+        if (has_next) stage(nxt, 0, buf ^ 1);
+
+        // Packed weight row (16*i + rho) of a 64-row group holds channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3), so
+        // lane group fq owns the 8 consecutive channels 32*ip + 8*fq .. +7 (accumulators 2ip and 2ip+1).
+        const int chBlk = cur.chTile * BM + wc * 16 * CB;     // first channel (within the group-block) of this wave
+        const int chGlob0 = cur.gb * p.cout_blk;
+        const int mBase = cur.tileP0 + wp * 16 * PB + fr;
+        float sc[NPAIR][8], sf[NPAIR][8];
+        u32x4 rres[NPAIR][PB];                                  // 16-bit residual: 8 channels per (ip, j)
+        f32x4 rres32[DT == PCV_F32 ? NPAIR : 1][DT == PCV_F32 ? PB : 1][2];
+        if constexpr (!RAGGED) {
 #pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            const int m = tileP0 + wp * 16 * PB + 16 * j + fr;
-            if (m >= p.M) continue;
-            const size_t eoff = (size_t)m * p.Cout_total + chg;
-            float v[8];
+            for (int ip = 0; ip < NPAIR; ++ip) {
+                const int ch0 = chBlk + 32 * ip + 8 * fq;
+                const int chg = chGlob0 + ch0;
+                f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+                if (ch0 < p.Cout) {
+                    if (p.scale != nullptr) {
+                        s0 = *reinterpret_cast<const f32x4*>(p.scale + chg);
+                        s1 = *reinterpret_cast<const f32x4*>(p.scale + chg + 4);
+                    }
+                    if (p.shift != nullptr) {
+                        h0 = *reinterpret_cast<const f32x4*>(p.shift + chg);
+                        h1 = *reinterpret_cast<const f32x4*>(p.shift + chg + 4);
+                    }
+                }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[2 * ip][j][e] * sc[e] + sf[e];
-                v[4 + e] = acc[2 * ip + 1][j][e] * sc[4 + e] + sf[4 + e];
-            }
-            if (p.act != PCV_ACT_NONE) {
+                for (int e = 0; e < 4; ++e) { sc[ip][e] = s0[e]; sc[ip][4 + e] = s1[e]; sf[ip][e] = h0[e]; sf[ip][4 + e] = h1[e]; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-            }
-            if (p.res != nullptr) {
-                if constexpr (RAGGED) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (ch0 + e < p.Cout) v[e] += load_elem<DT>(p.res, eoff + e);
-                } else if constexpr (DT == PCV_F32) {
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + eoff);
-                    const f32x4 r1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + eoff + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-                } else {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.res) + eoff);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo, hi;
-                        unpack2<DT>(r[e], lo, hi);
-                        v[2 * e] += lo;
-                        v[2 * e + 1] += hi;
+                for (int j = 0; j < PB; ++j) {
+                    const int m = mBase + 16 * j;
+                    const bool ok = p.res != nullptr && ch0 < p.Cout && m < p.M;
+                    const size_t eoff = (size_t)m * p.Cout_total + chg;
+                    if constexpr (DT == PCV_F32) {
+                        rres32[ip][j][0] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + eoff)
+                                              : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        rres32[ip][j][1] = ok ? *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + eoff + 4)
+                                              : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        rres[ip][j] = ok ? *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.res) + eoff)
+                                         : (u32x4){0u, 0u, 0u, 0u};
                     }
                 }
             }
-            if (p.post_act != PCV_ACT_NONE) {
+        }
+
+        compute(buf);
+
+        // ---- epilogue: scale/shift -> act -> (+residual) -> post_act -> NHWC store ----------------------------
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.post_act);
-            }
+        for (int ip = 0; ip < NPAIR; ++ip) {
+            const int ch0 = chBlk + 32 * ip + 8 * fq;           // within the group-block
+            if (ch0 >= p.Cout) continue;
+            const int chg = chGlob0 + ch0;                      // global channel
             if constexpr (RAGGED) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ch0 + e < p.Cout) store_elem<OT>(p.y, eoff + e, v[e]);
-            } else if constexpr (OT == PCV_F32) {
-                float* yp = reinterpret_cast<float*>(p.y) + eoff;
-                *reinterpret_cast<f32x4*>(yp) = (f32x4){v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(yp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-            } else {
-                u32x4 o;
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = ch0 + e < p.Cout;
+                    sc[ip][e] = ok ? (p.scale ? p.scale[chg + e] : 1.f) : 0.f;
+                    sf[ip][e] = ok ? (p.shift ? p.shift[chg + e] : 0.f) : 0.f;
+                }
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2<OT>(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + eoff) = o;
+            for (int j = 0; j < PB; ++j) {
+                const int m = mBase + 16 * j;
+                if (m >= p.M) continue;
+                const size_t eoff = (size_t)m * p.Cout_total + chg;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
+                    v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
+                }
+                if (p.act != PCV_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
+                }
+                if (p.res != nullptr) {
+                    if constexpr (RAGGED) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (ch0 + e < p.Cout) v[e] += load_elem<DT>(p.res, eoff + e);
+                    } else if constexpr (DT == PCV_F32) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += rres32[ip][j][0][e]; v[4 + e] += rres32[ip][j][1][e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float lo, hi;
+                            unpack2<DT>(rres[ip][j][e], lo, hi);
+                            v[2 * e] += lo;
+                            v[2 * e + 1] += hi;
+                        }
+                    }
+                }
+                if (p.post_act != PCV_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.post_act);
+                }
+                if constexpr (RAGGED) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ch0 + e < p.Cout) store_elem<OT>(p.y, eoff + e, v[e]);
+                } else if constexpr (OT == PCV_F32) {
+                    float* yp = reinterpret_cast<float*>(p.y) + eoff;
+                    *reinterpret_cast<f32x4*>(yp) = (f32x4){v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(yp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack2<OT>(v[2 * e], v[2 * e + 1]);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + eoff) = o;
+                }
             }
         }
+        if (!has_next) break;
+        zero_acc();
+        cur = nxt;
+        tile = ntile;
+        buf ^= 1;
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }

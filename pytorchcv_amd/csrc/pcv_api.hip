@@ -5,6 +5,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "dwconv.hpp"
@@ -13,16 +14,14 @@
 
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
-IGEMM_DECLARE(PCV_F32, PCV_F32, 2, 4, 1, 4, false)
-IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 1, 4, false)
-IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 2, 2, false)
-IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 4, 1, false)
-IGEMM_DECLARE(PCV_F32, PCV_F32, 4, 4, 2, 2, true)
+IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
 
 struct pcv_ctx {
     int device = 0;
     std::string err;
     int num_cu = 256;
+    int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
+    int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
 
 static thread_local std::string g_create_err;
@@ -178,47 +177,69 @@ static const TileInfo kTiles[TILE_COUNT] = {
 };
 typedef void (*igemm_fn)(const IgemmParams);
 
-template <int DT, int OT, bool RG> static igemm_fn igemm_for_tile(int tile) {
+template <int DT, int KHW> static igemm_fn igemm_for_tile(int tile) {
     switch (tile) {
-        case TILE_C32: return igemm_conv_kernel<DT, OT, 2, 4, 1, 4, RG>;
-        case TILE_C64: return igemm_conv_kernel<DT, OT, 4, 4, 1, 4, RG>;
-        case TILE_C128: return igemm_conv_kernel<DT, OT, 4, 4, 2, 2, RG>;
-        default: return igemm_conv_kernel<DT, OT, 4, 4, 4, 1, RG>;
+        case TILE_C32: return igemm_conv_kernel<DT, DT, 2, 4, 1, 4, false, KHW>;
+        case TILE_C64: return igemm_conv_kernel<DT, DT, 4, 4, 1, 4, false, KHW>;
+        case TILE_C128: return igemm_conv_kernel<DT, DT, 4, 4, 2, 2, false, KHW>;
+        default: return igemm_conv_kernel<DT, DT, 4, 4, 4, 1, false, KHW>;
     }
 }
+template <int DT> static igemm_fn igemm_for_taps(int tile, int khw) {
+    if (khw == 1) return igemm_for_tile<DT, 1>(tile);
+    if (khw == 9) return igemm_for_tile<DT, 9>(tile);
+    return igemm_for_tile<DT, 0>(tile);
+}
 // Non-ragged kernels store in the activation dtype; the ragged / fp32-output variants exist only on the 128x128 tile
-// (classifier logits, odd channel counts).
-static igemm_fn pick_igemm(int dt, int ot, bool ragged, int tile) {
+// (classifier logits, odd channel counts) with descriptor-driven taps.
+static igemm_fn pick_igemm(int dt, int ot, bool ragged, int tile, int khw) {
     if (!ragged && ot == dt) {
-        if (dt == PCV_BF16) return igemm_for_tile<PCV_BF16, PCV_BF16, false>(tile);
-        if (dt == PCV_F16) return igemm_for_tile<PCV_F16, PCV_F16, false>(tile);
-        return igemm_for_tile<PCV_F32, PCV_F32, false>(tile);
+        if (dt == PCV_BF16) return igemm_for_taps<PCV_BF16>(tile, khw);
+        if (dt == PCV_F16) return igemm_for_taps<PCV_F16>(tile, khw);
+        return igemm_for_taps<PCV_F32>(tile, khw);
     }
     if (tile != TILE_C128) return nullptr;
     if (ot == PCV_F32) {
-        if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_F32, 4, 4, 2, 2, true>;
-        if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F32, 4, 4, 2, 2, true>;
-        return igemm_conv_kernel<PCV_F32, PCV_F32, 4, 4, 2, 2, true>;
+        if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_F32, 4, 4, 2, 2, true, 0>;
+        if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F32, 4, 4, 2, 2, true, 0>;
+        return igemm_conv_kernel<PCV_F32, PCV_F32, 4, 4, 2, 2, true, 0>;
     }
-    if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_BF16, 4, 4, 2, 2, true>;
-    if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F16, 4, 4, 2, 2, true>;
+    if (dt == PCV_BF16) return igemm_conv_kernel<PCV_BF16, PCV_BF16, 4, 4, 2, 2, true, 0>;
+    if (dt == PCV_F16) return igemm_conv_kernel<PCV_F16, PCV_F16, 4, 4, 2, 2, true, 0>;
     return nullptr;
 }
 
+// Every instantiation gets its dynamic-LDS limit raised once; the resident blocks per CU (for persistent grid sizing)
+// come from the occupancy query (these kernels use < 80 SGPRs, where the query is exact - MI355X_MICROARCH.md).
+static int g_blocks_per_cu[3][2][TILE_COUNT][3];     // [dt][variant: 0 regular, 1 ragged/f32-out][tile][khw slot]
+static inline int khw_slot(int khw) { return khw == 1 ? 1 : (khw == 9 ? 2 : 0); }
+
 static int enable_big_lds(pcv_ctx* ctx) {
+    static const int khws[3] = {0, 1, 9};
     for (int dt = 0; dt < 3; ++dt)
         for (int tile = 0; tile < TILE_COUNT; ++tile)
-            for (int variant = 0; variant < 3; ++variant) {
-                igemm_fn f = variant == 0 ? pick_igemm(dt, dt, false, tile)
-                           : variant == 1 ? pick_igemm(dt, PCV_F32, true, tile)
-                                          : pick_igemm(dt, dt, true, tile);
-                if (f == nullptr) continue;
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(f),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[tile].lds));
-            }
+            for (int ks = 0; ks < 3; ++ks)
+                for (int variant = 0; variant < 3; ++variant) {
+                    if (variant != 0 && ks != 0) continue;
+                    igemm_fn f = variant == 0 ? pick_igemm(dt, dt, false, tile, khws[ks])
+                               : variant == 1 ? pick_igemm(dt, PCV_F32, true, tile, 0)
+                                              : pick_igemm(dt, dt, true, tile, 0);
+                    if (f == nullptr) continue;
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(f),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[tile].lds));
+                    int nb = 0;
+                    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(f),
+                                                                              kTiles[tile].threads, kTiles[tile].lds));
+                    if (nb < 1) nb = 1;
+                    if (std::getenv("PCV_AMD_DEBUG"))
+                        std::fprintf(stderr, "[pcv] igemm dt=%d tile=%d khw=%d variant=%d: %d blocks/CU\n", dt, tile, khws[ks], variant, nb);
+                    if (variant == 0) g_blocks_per_cu[dt][0][tile][ks] = nb;
+                    else g_blocks_per_cu[dt][1][tile][0] = nb;
+                }
     return PCV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
 // launch helpers (templates need C++ linkage)
 template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1><<<grid, 256, 0, s>>>(p);
@@ -269,6 +290,8 @@ int pcv_create(pcv_ctx** out, int device) {
     if (ctx == nullptr) return fail(nullptr, PCV_ERR_INVALID, "pcv_create: out of host memory");
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("PCV_AMD_PERSIST")) ctx->persist_mode = std::atoi(e);
+    if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
     int rc = enable_big_lds(ctx);
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
@@ -446,7 +469,13 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     else if (P.cout_blk <= 256) tile = TILE_C256;
     else tile = TILE_C128;
     if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
-    igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, ragged || d->out_dtype != d->dtype, tile);
+    const bool special = ragged || d->out_dtype != d->dtype;
+    int khw = 0;
+    if (!special && !P.pair && d->dil_h == 1 && d->dil_w == 1) {
+        if (d->kh == 1 && d->kw == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0) khw = 1;
+        else if (d->kh == 3 && d->kw == 3 && P.cin_blk % (8 * P.CE) == 0) khw = 9;
+    }
+    igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, special, tile, khw);
     if (!fn) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: no kernel for this dtype combination");
     const TileInfo& T = kTiles[tile];
 
@@ -487,7 +516,21 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     p.post_act = d->post_act;
     p.nPixTiles = (p.M + T.BP - 1) / T.BP;
     p.nChTiles = (P.cout_blk + T.BM - 1) / T.BM;
-    dim3 grid((unsigned)(p.nPixTiles * p.nChTiles), (unsigned)P.ngb);
+    p.ngb = P.ngb;
+    p.Cin = P.cin_blk;
+    p.ksteps_per_tap = P.cin_blk / (8 * P.CE) > 0 ? P.cin_blk / (8 * P.CE) : 1;
+    const long long nTiles = (long long)p.nPixTiles * p.nChTiles * P.ngb;
+    if (nTiles >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    p.nTiles = (int)nTiles;
+    // persistent grid: what is resident at once, a multiple of 8 so that every XCD gets the same number of blocks
+    const int bpc = special ? g_blocks_per_cu[d->dtype][1][tile][0] : g_blocks_per_cu[d->dtype][0][tile][khw_slot(khw)];
+    // Short K loops (HBM-bound 1x1 layers) run persistent, so that the next tile's loads overlap this tile's
+    // epilogue; long K loops run one tile per block (the dispatcher refills a CU while the finished block's stores drain).
+    const bool persistent = ctx->persist_mode == 1 || (ctx->persist_mode < 0 && P.nk <= ctx->persist_max_nk);
+    long long nblocks = persistent ? (long long)ctx->num_cu * bpc : nTiles;
+    if (nblocks > nTiles) nblocks = nTiles;
+    nblocks = (nblocks + 7) / 8 * 8;
+    dim3 grid((unsigned)nblocks);
     hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
