@@ -77,10 +77,13 @@ class ShardedInference(object):
                               device=y_local.device)
             dist.all_gather_into_tensor(out, y_local.contiguous(), group=self.group)
             return out
-        parts = [torch.empty((b - a,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
-                 for a, b in counts]
-        dist.all_gather(parts, y_local.contiguous(), group=self.group)
-        return torch.cat(parts)
+        # uneven shards: pad every rank's block to the largest one, one all-gather, then drop the padding rows
+        biggest = max(b - a for a, b in counts)
+        padded = torch.zeros((biggest,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+        padded[:y_local.shape[0]] = y_local
+        out = torch.empty((self.world * biggest,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+        dist.all_gather_into_tensor(out, padded, group=self.group)
+        return torch.cat([out[r * biggest:r * biggest + (b - a)] for r, (a, b) in enumerate(counts)])
 
     def __call__(self, x_global_or_local: torch.Tensor, already_sharded: bool = False) -> torch.Tensor:
         if already_sharded:
