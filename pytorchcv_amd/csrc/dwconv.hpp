@@ -4,12 +4,18 @@
 //           i.e. Conv2d(groups=C) + BatchNorm2d(eval) + ReLU6 of LinearBottleneck.conv2 (mobilenetv2.py:53-57).
 //
 // HBM-bound (3.4 FLOP/B): the job is to read every input byte once and write every output byte once with 16-byte
-// accesses. One thread owns 8 consecutive channels (one 16-byte NHWC chunk for the 16-bit types) of one output
-// column and walks DOWN the image keeping a KS x KS window of fp32 rows in registers, so per output row it loads
-// only the STRIDE new input rows (KS chunks each). Consecutive lanes = consecutive channel chunks, then
-// consecutive output columns: every wave-level load/store is one contiguous NHWC span; the +-1 column re-reads hit
-// the same lines in the vector L1.
+// accesses and enough of them in flight. One thread owns 8 consecutive channels (one 16-byte NHWC chunk at 16 bit) of
+// one output column and walks DOWN the image with a KS x KS fp32 window in registers, so per output row it loads only
+// the STRIDE new input rows (KS chunks each).
+//   * Loads are `buffer_load_dwordx4` with range checking: a padded (out-of-image) tap is an offset beyond
+//     num_records and returns zeros - no branches, so all loads of a step issue back to back.
+//   * Software prefetch: the rows needed by output row h+1 are requested before the FMAs of row h.
+//   * The window rotates by register renaming (the row loop is unrolled over the rotation period), no moves.
+//   * Consecutive lanes = consecutive channel chunks, then consecutive output columns: every wave-level access is one
+//     contiguous NHWC span; the +-1 column re-reads hit the same lines in the vector L1.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "pcv_common.hpp"
 
 struct DwParams {
@@ -19,6 +25,7 @@ struct DwParams {
     void* y;
     const float* scale;
     const float* shift;
+    uint32_t x_bytes;     // buffer num_records of x
     int N, H, W, C, Ho, Wo;
     int pt, pl;
     int C8;               // C / 8
@@ -53,8 +60,32 @@ template <int DT> __device__ __forceinline__ void store8(void* base, size_t eidx
     }
 }
 
+// raw 8-channel chunk as it comes from memory: 1 x 16 B (16-bit types) or 2 x 16 B (fp32)
+template <int DT> struct RawChunk { u32x4 q[DT == PCV_F32 ? 2 : 1]; };
+
+template <int DT> __device__ __forceinline__ void raw_to_f32(const RawChunk<DT>& r, float (&v)[8]) {
+    if constexpr (DT == PCV_F32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(r.q[0][e]); v[4 + e] = __uint_as_float(r.q[1][e]); }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unpack2<DT>(r.q[0][e], v[2 * e], v[2 * e + 1]);
+    }
+}
+
+template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
 template <int DT, int KS, int S>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ES = Elem<DT>::BYTES;
+    constexpr int KEEP = KS > S ? KS - S : 0;       // rows shared by consecutive output rows
+    constexpr int NEW = KS - KEEP;                  // rows fetched per output row
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= p.total) return;
     const int c8 = (int)(idx % p.C8);
@@ -67,76 +98,95 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     const int ho_begin = seg * p.TH;
     const int ho_end = min(p.Ho, ho_begin + p.TH);
 
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+
     float wgt[KS * KS][8];
 #pragma unroll
     for (int k = 0; k < KS * KS; ++k) load8<DT>(p.w, (size_t)k * p.C + c0, wgt[k]);
     float sc[8], sf[8];
-    {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p.scale + c0), b = *reinterpret_cast<const f32x4*>(p.scale + c0 + 4);
-        const f32x4 c = *reinterpret_cast<const f32x4*>(p.shift + c0), d = *reinterpret_cast<const f32x4*>(p.shift + c0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[e] = a[e]; sc[4 + e] = b[e]; sf[e] = c[e]; sf[4 + e] = d[e]; }
-    }
+    load8<PCV_F32>(p.scale, c0, sc);
+    load8<PCV_F32>(p.shift, c0, sf);
+    const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
 
+    // per-column byte offsets (relative to the row start) or "invalid"
     const int wi0 = wo * S - p.pl;
-    bool colok[KS];
+    uint32_t coloff[KS];
 #pragma unroll
-    for (int q = 0; q < KS; ++q) colok[q] = (unsigned)(wi0 + q) < (unsigned)p.W;
+    for (int q = 0; q < KS; ++q)
+        coloff[q] = (unsigned)(wi0 + q) < (unsigned)p.W ? (uint32_t)(((wi0 + q) * p.C + c0) * ES) : 0x80000000u;
+    const uint32_t rowbytes = (uint32_t)(p.W * p.C * ES);
+    const uint32_t imgoff = (uint32_t)n * (uint32_t)p.H * rowbytes;
 
-    float win[KS][KS][8];
-    auto load_row = [&](int hi, float (&row)[KS][8]) {
+    auto fetch_row = [&](int hi, RawChunk<DT> (&row)[KS]) {
         const bool rowok = (unsigned)hi < (unsigned)p.H;
+        const uint32_t rbase = imgoff + (uint32_t)hi * rowbytes;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
-            if (rowok && colok[q]) {
-                load8<DT>(p.x, (((size_t)n * p.H + hi) * p.W + (wi0 + q)) * p.C + c0, row[q]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) row[q][e] = 0.f;
-            }
+            const uint32_t off = (rowok && coloff[q] != 0x80000000u) ? rbase + coloff[q] : 0x80000000u;
+            row[q].q[0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+            if constexpr (DT == PCV_F32) row[q].q[1] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 16, 0);
         }
     };
 
-    // prologue: the KS-S rows shared with the first output row
+    float win[KS][KS][8];                // slot-indexed rows; row r of the current window lives in slot (r + S*phase) % KS
+    RawChunk<DT> raw[NEW][KS];           // rows in flight for the next output row
+
+    // prologue: the KEEP rows shared with the first output row go straight into the window, its NEW rows into `raw`
     int hi = ho_begin * S - p.pt;
+    {
+        RawChunk<DT> tmp[KEEP > 0 ? KEEP : 1][KS];
 #pragma unroll
-    for (int r = 0; r < KS - S; ++r) load_row(hi + r, win[r + S]);
-
-    for (int ho = ho_begin; ho < ho_end; ++ho, hi += S) {
-        // slide: rows S..KS-1 become 0..KS-S-1, then load the S new rows at the bottom
+        for (int r = 0; r < KEEP; ++r) fetch_row(hi + r, tmp[r]);
 #pragma unroll
-        for (int r = 0; r < KS - S; ++r)
+        for (int r = 0; r < NEW; ++r) fetch_row(hi + KEEP + r, raw[r]);
 #pragma unroll
-            for (int q = 0; q < KS; ++q)
+        for (int r = 0; r < KEEP; ++r)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) win[r][q][e] = win[r + S][q][e];
-#pragma unroll
-        for (int r = KS - S; r < KS; ++r) load_row(hi + r, win[r]);
-
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int r = 0; r < KS; ++r)
-#pragma unroll
-            for (int q = 0; q < KS; ++q)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(win[r][q][e], wgt[r * KS + q][e], acc[e]);
-
-        const size_t eoff = (((size_t)n * p.Ho + ho) * p.Wo + wo) * p.C + c0;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = apply_act(acc[e] * sc[e] + sf[e], p.act);
-        if (p.res != nullptr) {
-            float r8[8];
-            load8<DT>(p.res, eoff, r8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r8[e];
-        }
-        if (p.post_act != PCV_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.post_act);
-        }
-        store8<DT>(p.y, eoff, v);
+            for (int q = 0; q < KS; ++q) raw_to_f32<DT>(tmp[r][q], win[r][q]);
     }
+
+    int ho = ho_begin;
+    while (ho < ho_end) {
+        static_for<KS>([&](auto PHC) {
+            constexpr int PH = decltype(PHC)::value;
+            if (ho < ho_end) {
+                // rows KEEP..KS-1 of this window arrive from `raw`
+#pragma unroll
+                for (int r = 0; r < NEW; ++r)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) raw_to_f32<DT>(raw[r][q], win[(KEEP + r + S * PH) % KS][q]);
+                // request the next output row's new rows before doing this row's arithmetic
+                if (ho + 1 < ho_end) {
+#pragma unroll
+                    for (int r = 0; r < NEW; ++r) fetch_row(hi + S + KEEP + r, raw[r]);
+                }
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int r = 0; r < KS; ++r)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(win[(r + S * PH) % KS][q][e], wgt[r * KS + q][e], acc[e]);
+
+                const size_t eoff = (((size_t)n * p.Ho + ho) * p.Wo + wo) * p.C + c0;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[e] * sc[e] + sf[e];
+                apply_act8(v, act);
+                if (p.res != nullptr) {
+                    float r8[8];
+                    load8<DT>(p.res, eoff, r8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                }
+                apply_act8(v, pact);
+                store8<DT>(p.y, eoff, v);
+                ++ho;
+                hi += S;
+            }
+        });
+    }
+#endif  // __HIP_DEVICE_COMPILE__
 }

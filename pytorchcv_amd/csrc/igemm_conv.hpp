@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
         }
     };
 
+    const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
     zero_acc();
     TileState cur, nxt;
     setup(tile, cur);
@@ -339,10 +340,7 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
                     v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
                     v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
                 }
-                if (p.act != PCV_ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.act);
-                }
+                apply_act8(v, act);
                 if (p.res != nullptr) {
                     if constexpr (RAGGED) {
 #pragma unroll
@@ -361,10 +359,7 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
                         }
                     }
                 }
-                if (p.post_act != PCV_ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], p.post_act);
-                }
+                apply_act8(v, pact);
                 if constexpr (RAGGED) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)

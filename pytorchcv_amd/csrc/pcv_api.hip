@@ -555,6 +555,10 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.scale = scale;
     p.shift = shift;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin;
+    const unsigned long long xbytes = (unsigned long long)d->N * d->H * d->W * d->Cin * esize(d->dtype);
+    if (xbytes >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_dwconv2d_fused: input exceeds the 2 GiB window of one launch; split the batch");
+    p.x_bytes = (uint32_t)xbytes;
     p.Ho = (d->H + d->pad_t + d->pad_b - (d->kh - 1) - 1) / d->stride_h + 1;
     p.Wo = (d->W + d->pad_l + d->pad_r - (d->kw - 1) - 1) / d->stride_w + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: empty output");

@@ -76,6 +76,30 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         default: return v;
     }
 }
+// The common activations (none / relu / relu6) are a clamp with launch-uniform bounds: two VALU ops, no branches in
+// the unrolled epilogues. Anything else takes the (uniform) slow branch once per 8-element group.
+struct ActClamp {
+    float lo, hi;
+    bool slow;
+    int code;
+};
+__device__ __forceinline__ ActClamp make_act(int act) {
+    ActClamp a;
+    a.code = act;
+    a.slow = act > PCV_ACT_RELU6;
+    a.lo = (act == PCV_ACT_RELU || act == PCV_ACT_RELU6) ? 0.f : -INFINITY;
+    a.hi = act == PCV_ACT_RELU6 ? 6.f : INFINITY;
+    return a;
+}
+__device__ __forceinline__ void apply_act8(float (&v)[8], const ActClamp& a) {
+    if (a.slow) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.code);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], a.lo), a.hi);
+    }
+}
 
 // ---- exact unsigned division by a launch-time constant, n < 2^31 ----------------------------------------
 struct FastDiv {
