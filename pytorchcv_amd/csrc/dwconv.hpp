@@ -73,6 +73,34 @@ template <int DT> __device__ __forceinline__ void raw_to_f32(const RawChunk<DT>&
     }
 }
 
+// 8 channels as 4 packed pairs: the FMAs below lower to v_pk_fma_f32 (two lanes of fp32 per instruction)
+template <int DT> __device__ __forceinline__ void raw_to_f32x2(const RawChunk<DT>& r, f32x2 (&v)[4]) {
+    if constexpr (DT == PCV_F32) {
+        v[0] = (f32x2){__uint_as_float(r.q[0][0]), __uint_as_float(r.q[0][1])};
+        v[1] = (f32x2){__uint_as_float(r.q[0][2]), __uint_as_float(r.q[0][3])};
+        v[2] = (f32x2){__uint_as_float(r.q[1][0]), __uint_as_float(r.q[1][1])};
+        v[3] = (f32x2){__uint_as_float(r.q[1][2]), __uint_as_float(r.q[1][3])};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float lo, hi;
+            unpack2<DT>(r.q[0][e], lo, hi);
+            v[e] = (f32x2){lo, hi};
+        }
+    }
+}
+
+// acc += a * b on two fp32 lanes per instruction. hipcc scalarises most `__builtin_elementwise_fma` on float2 here, so the
+// instruction is named directly (pure register-to-register, no memory, no hazards with the surrounding VALU code).
+__device__ __forceinline__ void pk_fma_acc(f32x2& acc, const f32x2& a, const f32x2& b) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ f32x2 pk_mul(const f32x2& a, const f32x2& b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int... I, typename F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
 }
@@ -80,7 +108,9 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
-template <int DT, int KS, int S>
+// FAST: both activations are none/relu/relu6 (a clamp); the general activation codes live in the FAST=false build so
+// that their transcendental code does not bloat the hot kernel.
+template <int DT, int KS, int S, bool FAST>
 __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = Elem<DT>::BYTES;
@@ -100,12 +130,22 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
 
-    float wgt[KS * KS][8];
+    f32x2 wgt[KS * KS][4];
 #pragma unroll
-    for (int k = 0; k < KS * KS; ++k) load8<DT>(p.w, (size_t)k * p.C + c0, wgt[k]);
-    float sc[8], sf[8];
-    load8<PCV_F32>(p.scale, c0, sc);
-    load8<PCV_F32>(p.shift, c0, sf);
+    for (int k = 0; k < KS * KS; ++k) {
+        float w8[8];
+        load8<DT>(p.w, (size_t)k * p.C + c0, w8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wgt[k][e] = (f32x2){w8[2 * e], w8[2 * e + 1]};
+    }
+    f32x2 sc[4], sf[4];
+    {
+        float a8[8], b8[8];
+        load8<PCV_F32>(p.scale, c0, a8);
+        load8<PCV_F32>(p.shift, c0, b8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[e] = (f32x2){a8[2 * e], a8[2 * e + 1]}; sf[e] = (f32x2){b8[2 * e], b8[2 * e + 1]}; }
+    }
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
 
     // per-column byte offsets (relative to the row start) or "invalid"
@@ -128,60 +168,79 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
         }
     };
 
-    float win[KS][KS][8];                // slot-indexed rows; row r of the current window lives in slot (r + S*phase) % KS
-    RawChunk<DT> raw[NEW][KS];           // rows in flight for the next output row
+    f32x2 win[KS][KS][4];                // slot-indexed rows; row r of the current window lives in slot (r + S*phase) % KS
+    constexpr int PD = (KS == 3 && S == 1) ? 3 : 1;   // prefetch depth in output rows; divides the unroll period (static ring slots)
+    RawChunk<DT> raw[PD][NEW][KS];       // ring: raw[t % PD] holds the NEW rows of output row t (relative to ho_begin)
 
-    // prologue: the KEEP rows shared with the first output row go straight into the window, its NEW rows into `raw`
-    int hi = ho_begin * S - p.pt;
+    // prologue: the KEEP rows shared with the first output row go straight into the window; the NEW rows of the first
+    // PD output rows are requested up front
+    const int hi_first = ho_begin * S - p.pt;
     {
         RawChunk<DT> tmp[KEEP > 0 ? KEEP : 1][KS];
 #pragma unroll
-        for (int r = 0; r < KEEP; ++r) fetch_row(hi + r, tmp[r]);
+        for (int r = 0; r < KEEP; ++r) fetch_row(hi_first + r, tmp[r]);
 #pragma unroll
-        for (int r = 0; r < NEW; ++r) fetch_row(hi + KEEP + r, raw[r]);
+        for (int d = 0; d < PD; ++d) {
+            // rows beyond this thread's strip are not requested (offset forced invalid through hi = -1)
+            const bool need = ho_begin + d < ho_end;
+#pragma unroll
+            for (int r = 0; r < NEW; ++r) fetch_row(need ? hi_first + d * S + KEEP + r : -1, raw[d][r]);
+        }
 #pragma unroll
         for (int r = 0; r < KEEP; ++r)
 #pragma unroll
-            for (int q = 0; q < KS; ++q) raw_to_f32<DT>(tmp[r][q], win[r][q]);
+            for (int q = 0; q < KS; ++q) raw_to_f32x2<DT>(tmp[r][q], win[r][q]);
     }
 
     int ho = ho_begin;
+    int hi = hi_first;
     while (ho < ho_end) {
         static_for<KS>([&](auto PHC) {
             constexpr int PH = decltype(PHC)::value;
             if (ho < ho_end) {
-                // rows KEEP..KS-1 of this window arrive from `raw`
+                // rows KEEP..KS-1 of this window arrive from the ring slot of this output row
 #pragma unroll
                 for (int r = 0; r < NEW; ++r)
 #pragma unroll
-                    for (int q = 0; q < KS; ++q) raw_to_f32<DT>(raw[r][q], win[(KEEP + r + S * PH) % KS][q]);
-                // request the next output row's new rows before doing this row's arithmetic
-                if (ho + 1 < ho_end) {
+                    for (int q = 0; q < KS; ++q) raw_to_f32x2<DT>(raw[PH % PD][r][q], win[(KEEP + r + S * PH) % KS][q]);
+                // refill the slot with the rows of output row ho + PD before doing this row's arithmetic
+                {
+                    const bool need = ho + PD < ho_end;
 #pragma unroll
-                    for (int r = 0; r < NEW; ++r) fetch_row(hi + S + KEEP + r, raw[r]);
+                    for (int r = 0; r < NEW; ++r) fetch_row(need ? hi + PD * S + KEEP + r : -1, raw[PH % PD][r]);
                 }
-                float acc[8];
+                f32x2 acc[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+                for (int e = 0; e < 4; ++e) acc[e] = pk_mul(win[(S * PH) % KS][0][e], wgt[0][e]);
 #pragma unroll
                 for (int r = 0; r < KS; ++r)
 #pragma unroll
-                    for (int q = 0; q < KS; ++q)
+                    for (int q = 0; q < KS; ++q) {
+                        if (r == 0 && q == 0) continue;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(win[(r + S * PH) % KS][q][e], wgt[r * KS + q][e], acc[e]);
+                        for (int e = 0; e < 4; ++e)
+                            pk_fma_acc(acc[e], win[(r + S * PH) % KS][q][e], wgt[r * KS + q][e]);
+                    }
 
                 const size_t eoff = (((size_t)n * p.Ho + ho) * p.Wo + wo) * p.C + c0;
                 float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[e] * sc[e] + sf[e];
-                apply_act8(v, act);
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 t2 = sf[e];
+                    pk_fma_acc(t2, acc[e], sc[e]);
+                    v[2 * e] = t2[0];
+                    v[2 * e + 1] = t2[1];
+                }
+                if constexpr (FAST) clamp8(v, act); else apply_act8(v, act);
                 if (p.res != nullptr) {
                     float r8[8];
                     load8<DT>(p.res, eoff, r8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r8[e];
                 }
-                apply_act8(v, pact);
+                if (p.post_act != PCV_ACT_NONE) {
+                    if constexpr (FAST) clamp8(v, pact); else apply_act8(v, pact);
+                }
                 store8<DT>(p.y, eoff, v);
                 ++ho;
                 hi += S;

@@ -241,13 +241,16 @@ static int enable_big_lds(pcv_ctx* ctx) {
 
 // ---------------------------------------------------------------------------------------------------------
 // launch helpers (templates need C++ linkage)
-template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
-    if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1><<<grid, 256, 0, s>>>(p);
-    else if (d.kh == 3) dwconv_kernel<DT, 3, 2><<<grid, 256, 0, s>>>(p);
-    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1><<<grid, 256, 0, s>>>(p);
-    else dwconv_kernel<DT, 5, 2><<<grid, 256, 0, s>>>(p);
+template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
+    if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
+    else if (d.kh == 3) dwconv_kernel<DT, 3, 2, FAST><<<grid, 256, 0, s>>>(p);
+    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1, FAST><<<grid, 256, 0, s>>>(p);
+    else dwconv_kernel<DT, 5, 2, FAST><<<grid, 256, 0, s>>>(p);
 }
-
+template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
+    if (d.act <= PCV_ACT_RELU6 && d.post_act <= PCV_ACT_RELU6) launch_dw2<DT, true>(d, p, grid, s);
+    else launch_dw2<DT, false>(d, p, grid, s);
+}
 template <int DT> static void launch_mean(const void* x, void* y, int N, int HW, int C, int ot, hipStream_t s) {
     dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
     if (ot == PCV_F32) spatial_mean_kernel<DT, PCV_F32><<<grid, 256, 0, s>>>(x, y, HW, C);

@@ -91,13 +91,17 @@ __device__ __forceinline__ ActClamp make_act(int act) {
     a.hi = act == PCV_ACT_RELU6 ? 6.f : INFINITY;
     return a;
 }
+__device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);
+}
 __device__ __forceinline__ void apply_act8(float (&v)[8], const ActClamp& a) {
     if (a.slow) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.code);
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], a.lo), a.hi);
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);     // clamp in one VALU op
     }
 }
 
