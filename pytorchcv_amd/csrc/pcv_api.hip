@@ -469,7 +469,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     else if (P.cout_blk <= 32) tile = TILE_C32;
     else if (P.cout_blk <= 64) tile = TILE_C64;
     else if (P.cout_blk <= 128) tile = TILE_C128;
-    else if (P.cout_blk <= 256) tile = TILE_C256;
+    else if (P.cout_blk <= 256) tile = (d->kh * d->kw > 1) ? TILE_C128 : TILE_C256;   // 256x64 only pays for HBM-bound 1x1 (reads x once)
     else tile = TILE_C128;
     if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
     const bool special = ragged || d->out_dtype != d->dtype;
