@@ -57,6 +57,7 @@ struct IgemmParams {
     int nTiles;             // nPixTiles * ngb * nChTiles
     int Cin;                // input channels per group-block (KHW == 1: chunks beyond it are zero-filled)
     int ksteps_per_tap;     // KHW == 9: K-steps per filter tap (= cin_blk / elements per K-step)
+    int korder;             // KHW == 9: 0 = K ordered (r, q, slice), 1 = (r, slice, q)
 };
 
 template <int DT> struct Mma;
@@ -178,6 +179,12 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
 
     // issue the LDS-DMA loads of K-step k of tile state S into stage `buf`
+    // KHW == 0: the K-chunk descriptor of a step is fetched one step ahead (`kd_next`), so that its global-load latency
+    // hides under the previous step's MFMAs instead of stalling - and draining - the DMA issue.
+    auto load_kdesc = [&](int k) -> u32x2 {
+        return *reinterpret_cast<const u32x2*>(p.ktab + 2 * (k * 8 + cs));
+    };
+    u32x2 kd_next = {0u, 0u};
     auto stage = [&](const TileState& S, int k, int buf) {
         char* sbase = smem + buf * STAGE;
 #pragma unroll
@@ -194,13 +201,22 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
             r = 0; q = 0;
             chunk_ok = c0 < p.Cin;
         } else if constexpr (KHW == 9) {
-            const int tap = k / p.ksteps_per_tap;             // uniform: a K-step never straddles taps here
-            const int c0 = (k - tap * p.ksteps_per_tap) * (8 * CE) + cs * CE;
-            r = (uint32_t)tap / 3u;
-            q = (uint32_t)tap - 3u * r;
+            int cslice;                                       // uniform: a K-step never straddles taps here
+            if (p.korder == 0) {                              // K = (r, q, slice)
+                const int tap = k / p.ksteps_per_tap;
+                cslice = k - tap * p.ksteps_per_tap;
+                r = (uint32_t)tap / 3u;
+                q = (uint32_t)tap - 3u * r;
+            } else {                                          // K = (r, slice, q): blobs packed for conv3x3_kernel
+                const int grp = k / 3;
+                q = (uint32_t)(k - 3 * grp);
+                r = (uint32_t)(grp / p.ksteps_per_tap);
+                cslice = grp - (int)r * p.ksteps_per_tap;
+            }
+            const int c0 = cslice * (8 * CE) + cs * CE;
             koff = ((int)r * p.Wpitch + (int)q) * p.Cpitch + c0;
         } else {
-            const u32x2 kd = *reinterpret_cast<const u32x2*>(p.ktab + 2 * (k * 8 + cs));
+            const u32x2 kd = kd_next;
             const int c0 = (int)(kd[0] & 0xFFFFu);
             r = (kd[0] >> 16) & 15u;
             q = (kd[0] >> 20) & 15u;
@@ -250,15 +266,18 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     zero_acc();
     TileState cur, nxt;
     setup(tile, cur);
-    stage(cur, 0, 0);
-    int buf = 0;
     const int nk = p.nk;
+    if constexpr (KHW == 0) kd_next = load_kdesc(0);
+    stage(cur, 0, 0);
+    if constexpr (KHW == 0) kd_next = load_kdesc(nk > 1 ? 1 : 0);
+    int buf = 0;
 
     while (true) {
         // ---- K-steps 0 .. nk-2: tight loop, one barrier each --------------------------------------------------
         for (int k = 0; k + 1 < nk; ++k) {
             __syncthreads();                   // DMA(k) landed for every wave; the other stage is free again
             stage(cur, k + 1, buf ^ 1);
+            if constexpr (KHW == 0) kd_next = load_kdesc(k + 2 < nk ? k + 2 : 0);    // (k+2 == nk: next tile's step 0)
             compute(buf);
             buf ^= 1;
         }
@@ -268,6 +287,7 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
         if (has_next) setup(ntile, nxt);       // address math overlaps the DMA wait
         __syncthreads();
         if (has_next) stage(nxt, 0, buf ^ 1);
+        if constexpr (KHW == 0) kd_next = load_kdesc(nk > 1 ? 1 : 0);
 
         // Packed weight row (16*i + rho) of a 64-row group holds channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3), so
         // lane group fq owns the 8 consecutive channels 32*ip + 8*fq .. +7 (accumulators 2ip and 2ip+1).

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
+#include "conv3x3_inst.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 
@@ -15,12 +16,17 @@
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
 IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
+CONV3_INSTANCES(CONV3_DECLARE, PCV_BF16)
+CONV3_INSTANCES(CONV3_DECLARE, PCV_F16)
+CONV3_INSTANCES(CONV3_DECLARE, PCV_F32)
 
 struct pcv_ctx {
     int device = 0;
     std::string err;
     int num_cu = 256;
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
+    int use_conv3 = 1;          // dedicated 3x3 kernel (PCV_AMD_CONV3=0 falls back to the generic implicit GEMM)
+    int force_conv3_cfg = -1;   // PCV_AMD_CONV3_CFG: tuning only
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
 
@@ -46,6 +52,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // Convolution plan: everything that depends on the descriptor but not on the data pointers.
 // ---------------------------------------------------------------------------------------------------------
 struct ConvPlan {
+    bool conv3 = false;       // dedicated 3x3/s1/p1 kernel: K ordered (filter row, 128-byte channel slice, filter column)
     int ES = 2, CE = 8;
     bool pair = false;        // stem scheme: x_cpitch == 4 at 16 bit, one chunk = two pixels x 4 channels
     int Ho = 0, Wo = 0;
@@ -90,6 +97,10 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
     P.cout_blk = gpb * P.Cg_out;
     if (d.groups == 1) P.cin_blk = d.Cin;
     P.wrows = round_up(P.cout_blk, 32);
+
+    P.conv3 = d.groups == 1 && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+              d.pad_t == 1 && d.pad_l == 1 && d.pad_b == 1 && d.pad_r == 1 && d.Cin % (8 * P.CE) == 0 && cpitch == d.Cin &&
+              (d.x_wpitch <= 0 || d.x_wpitch == d.W) && d.out_dtype == d.dtype && d.Cout % 8 == 0;
 
     // taps
     if (P.pair) {
@@ -146,6 +157,16 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
                     }
                     put(0, r, q, P.dy[r], P.dx[q]);
                 }
+        } else if (P.conv3) {
+            const int slices = d.Cin / (8 * P.CE);
+            for (int r = 0; r < 3; ++r)
+                for (int cs = 0; cs < slices; ++cs)
+                    for (int q = 0; q < 3; ++q)
+                        for (int cc = cs * 8; cc < cs * 8 + 8; ++cc) {
+                            for (int e = 0; e < P.CE; ++e)
+                                P.ksrc[(size_t)j * P.CE + e] = (uint32_t)(cc * P.CE + e) | ((uint32_t)(r * 3 + q) << 16);
+                            put(cc * P.CE, r, q, P.dy[r], P.dx[q]);
+                        }
         } else {
             const int cchunks = (P.cin_blk + P.CE - 1) / P.CE;
             for (int r = 0; r < P.nR; ++r)
@@ -240,6 +261,39 @@ static int enable_big_lds(pcv_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// ---- dedicated 3x3 kernel table ----------------------------------------------------------------------------------
+enum Conv3Cfg { C3_128x256 = 0, C3_64x512 = 1, C3_COUNT = 2 };
+struct Conv3Info { int BM, BP, threads, lds; };
+static const Conv3Info kConv3[C3_COUNT] = {
+    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 8) * 128},
+    {64, 512, 512, 3 * 64 * 128 + 2 * (512 + 8) * 128},
+};
+typedef void (*conv3_fn)(const Conv3Params);
+template <int DT> static conv3_fn conv3_for(int cfg) {
+    return cfg == C3_128x256 ? conv3x3_kernel<DT, 2, 4> : conv3x3_kernel<DT, 1, 8>;
+}
+static conv3_fn pick_conv3(int dt, int cfg) {
+    if (dt == PCV_BF16) return conv3_for<PCV_BF16>(cfg);
+    if (dt == PCV_F16) return conv3_for<PCV_F16>(cfg);
+    return conv3_for<PCV_F32>(cfg);
+}
+static int g_conv3_blocks_per_cu[3][C3_COUNT];
+static int enable_conv3(pcv_ctx* ctx) {
+    for (int dt = 0; dt < 3; ++dt)
+        for (int cfg = 0; cfg < C3_COUNT; ++cfg) {
+            conv3_fn f = pick_conv3(dt, cfg);
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kConv3[cfg].lds));
+            int nb = 0;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(f),
+                                                                      kConv3[cfg].threads, kConv3[cfg].lds));
+            g_conv3_blocks_per_cu[dt][cfg] = nb < 1 ? 1 : nb;
+            if (std::getenv("PCV_AMD_DEBUG"))
+                std::fprintf(stderr, "[pcv] conv3x3 dt=%d cfg=%d: %d blocks/CU\n", dt, cfg, nb);
+        }
+    return PCV_OK;
+}
+
 // launch helpers (templates need C++ linkage)
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
@@ -295,7 +349,10 @@ int pcv_create(pcv_ctx** out, int device) {
     ctx->num_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("PCV_AMD_PERSIST")) ctx->persist_mode = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
+    if (const char* e = std::getenv("PCV_AMD_CONV3")) ctx->use_conv3 = std::atoi(e);
+    if (const char* e = std::getenv("PCV_AMD_CONV3_CFG")) ctx->force_conv3_cfg = std::atoi(e);
     int rc = enable_big_lds(ctx);
+    if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
         delete ctx;
@@ -463,6 +520,38 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
 
+    bool take_conv3 = P.conv3 && ctx->use_conv3;
+    if (take_conv3 && ctx->force_conv3_cfg < 0) {
+        const int c3 = d->Cout <= 64 ? C3_64x512 : C3_128x256;
+        const long long tiles = ((long long)((M64 + kConv3[c3].BP - 1) / kConv3[c3].BP)) * ((d->Cout + kConv3[c3].BM - 1) / kConv3[c3].BM);
+        take_conv3 = tiles * 10 >= (long long)ctx->num_cu * 9;      // fewer tiles than CUs: the 4-wave generic tiles fill better
+    }
+    if (take_conv3) {
+        Conv3Params q;
+        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
+        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
+        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.Cout = d->Cout;
+        q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.CS = d->Cin / (8 * P.CE);
+        q.Kpad = P.Kpad;
+        q.act = d->act; q.post_act = d->post_act;
+        int cfg = d->Cout <= 64 ? C3_64x512 : C3_128x256;
+        if (ctx->force_conv3_cfg >= 0 && ctx->force_conv3_cfg < C3_COUNT) cfg = ctx->force_conv3_cfg;
+        const Conv3Info& T3 = kConv3[cfg];
+        q.nChTiles = (d->Cout + T3.BM - 1) / T3.BM;
+        const long long nT = ((M64 + T3.BP - 1) / T3.BP) * q.nChTiles;
+        q.nTiles = (int)nT;
+        long long nb = (long long)ctx->num_cu * g_conv3_blocks_per_cu[d->dtype][cfg];
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        hipLaunchKernelGGL(pick_conv3(d->dtype, cfg), dim3((unsigned)nb), dim3(T3.threads), T3.lds, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
+
     const bool ragged = (d->Cout % 8 != 0) || (P.cout_blk % 8 != 0);
     int tile;
     if (ragged || d->out_dtype != d->dtype) tile = TILE_C128;
@@ -522,6 +611,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     p.ngb = P.ngb;
     p.Cin = P.cin_blk;
     p.ksteps_per_tap = P.cin_blk / (8 * P.CE) > 0 ? P.cin_blk / (8 * P.CE) : 1;
+    p.korder = P.conv3 ? 1 : 0;
     const long long nTiles = (long long)p.nPixTiles * p.nChTiles * P.ngb;
     if (nTiles >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
     p.nTiles = (int)nTiles;

@@ -107,3 +107,43 @@ def test_train_mode_is_refused(cuda_device):
     blk = util.build_block(case).to(cuda_device).train()
     with pytest.raises(RuntimeError, match="eval"):
         blk(torch.zeros(1, 32, 4, 4, device=cuda_device))
+
+
+# ---- dedicated 3x3 kernel: shapes that exercise every tile configuration, tile tails and image borders -------------
+_CONV3_SHAPES = [
+    # (N, C, Cout, H, W, residual)
+    (2, 64, 64, 56, 56, False),      # 64ch x 512px tiles, M = 6272 (12.25 tiles)
+    (3, 128, 128, 28, 28, True),     # 128x128 / 128x256, M = 2352
+    (2, 256, 256, 14, 14, True),     # two channel tiles
+    (5, 512, 512, 7, 7, False),      # images smaller than a tile: many image borders inside one tile
+    (1, 64, 192, 10, 14, False),     # H != W, Cout not a multiple of the 128-channel tile
+    (40, 128, 64, 9, 5, True),       # tiny odd maps, several tiles, 64-channel config with residual
+]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
+def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, cuda_device):
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, C, Cout, H, W, use_res = shape
+    blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=77)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=21)
+    res = util.synth_input(N, Cout, H, W, seed=22) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        y = engine.to_nchw(blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)).cpu()
+    q = refnet.Quant(None if dtype == "fp32" else dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None,
+                            post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    if dtype == "fp32":
+        assert float(d.max()) <= 1e-3
+    else:
+        assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
