@@ -76,6 +76,9 @@ int pcv_abi_version(void);
 int pcv_create(pcv_ctx** out, int device);
 int pcv_destroy(pcv_ctx* ctx);
 const char* pcv_last_error(const pcv_ctx* ctx);     /* ctx may be NULL: returns the last creation error */
+/* Tuning/debug switches ("persist", "conv3", "conv3_cfg", ...; also settable as PCV_AMD_* environment variables before
+ * pcv_create). They select among kernels that compute the same result; nothing in the reference corresponds to them. */
+int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value);
 
 /* ---- layout: the only NCHW-facing calls ---------------------------------------------------------------- */
 /* x: fp32 NCHW [N,C,H,W] (what callers hand to `net(x)`, resnet.py:333) -> y: NHWC [N,H,wpitch,cpitch] in dtype,

@@ -37,6 +37,7 @@ struct Conv3Params {
     int Kpad;               // packed row length in elements
     int act, post_act;
     int nChTiles, nTiles;
+    int flags;              // tuning switches (bit 0: lgkmcnt(0) before every barrier, bit 1: s_setprio around MFMA clusters)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -47,9 +48,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // activation tile double-buffered per (r, cs) group, prefetch distance 2 K-steps.
 //
 // Schedule of one group g = (r, cs) - straight-line, all wait counts are compile-time constants:
-//   q=0:  wait vmcnt(WL)     ; barrier ; issue W(g, q=2)                    ; MFMA(g, 0)
-//   q=1:  wait vmcnt(WL)     ; barrier ; issue W(g+1, q=0) + X(g+1)         ; MFMA(g, 1)
-//   q=2:  wait vmcnt(WL+XL)  ; barrier ; issue W(g+1, q=1)                  ; MFMA(g, 2)
+//   q=0:  wait vmcnt(WL)     ; barrier ; issue W(g, q=2) then X(g+1)        ; MFMA(g, 0)
+//   q=1:  wait vmcnt(WL+XL)  ; barrier ; issue W(g+1, q=0)                  ; MFMA(g, 1)     [X(g+1) stays in flight]
+//   q=2:  wait vmcnt(WL+XL)  ; barrier ; issue W(g+1, q=1)                  ; MFMA(g, 2)     [X(g+1) stays in flight]
 // (vmcnt(N): everything older than the N youngest VMEM ops of this wave has landed; ops issued later - epilogue
 // stores - only make the wait stricter.) "g+1" of a tile's last group is group 0 of the block's next tile.
 template <int DT, int WC, int WP>
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
     constexpr int XL = (XPIECES + NW - 1) / NW;    // activation DMA instructions per thread per group
     constexpr int WL = BM / (8 * NW);              // weight DMA instructions per thread per step
     constexpr int WRING = 3 * BM * 128;
+    constexpr int ZROW = WRING + 2 * XR * 128;     // one 128-byte row of zeros: what a padded tap reads
     static_assert(BM % (8 * NW) == 0, "weight tile must split evenly over the waves");
     typedef typename Mma<DT>::frag frag;
 
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
     int tile = xcd * perXcd + (int)(blockIdx.x >> 3);
     const int tend = min(p.nTiles, (xcd + 1) * perXcd);
     if (tile >= tend) return;
+
+    if (tid < 8) *reinterpret_cast<u32x4*>(smem + ZROW + 16 * tid) = (u32x4){0u, 0u, 0u, 0u};   // visible after the first barrier
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
         const char* wbase = smem + q * (BM * 128) + wfrag;
         const char* xbase = smem + WRING + xb * (XR * 128) + (xrow0 + q) * 128;
         const int rsw = (fr + q) & 7;                  // swizzle term of the shifted activation row
+        if (p.flags & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int wsw = ((fq + 4 * kk) ^ (fr & 7)) << 4;
@@ -197,8 +202,12 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
 #pragma unroll
                 for (int j = 0; j < PB; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
         }
+        if (p.flags & 2) __builtin_amdgcn_s_setprio(0);
     };
     auto sync = [&](auto NC) {
+        // this wave's LDS reads of the previous step are complete (the slot they read may be refilled after the barrier),
+        // its DMA of the coming step has landed; then everybody's
+        if (p.flags & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<decltype(NC)::value>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -222,10 +231,10 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
         for (int g = 0; g + 1 < G; ++g) {
             sync(std::integral_constant<int, WL>{});
             issue_w(cur, g, 2);
-            compute(I0{}, xb);
-            sync(std::integral_constant<int, WL>{});
-            issue_w(cur, g + 1, 0);
             issue_x(cur, g + 1, xb ^ 1);
+            compute(I0{}, xb);
+            sync(std::integral_constant<int, WL + XL>{});
+            issue_w(cur, g + 1, 0);
             compute(I1{}, xb);
             sync(std::integral_constant<int, WL + XL>{});
             issue_w(cur, g + 1, 1);
@@ -238,11 +247,13 @@ __global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params
         if (has_next) setup(ntile, nxt);
         sync(std::integral_constant<int, WL>{});
         issue_w(cur, G - 1, 2);
+        if (has_next) issue_x(nxt, 0, xb ^ 1);
         compute(I0{}, xb);
-        sync(std::integral_constant<int, WL>{});
         if (has_next) {
+            sync(std::integral_constant<int, WL + XL>{});
             issue_w(nxt, 0, 0);
-            issue_x(nxt, 0, xb ^ 1);
+        } else {
+            sync(std::integral_constant<int, WL>{});
         }
         compute(I1{}, xb);
         if (has_next) {

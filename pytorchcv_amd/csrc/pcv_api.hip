@@ -25,8 +25,10 @@ struct pcv_ctx {
     std::string err;
     int num_cu = 256;
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
-    int use_conv3 = 1;          // dedicated 3x3 kernel (PCV_AMD_CONV3=0 falls back to the generic implicit GEMM)
+    int use_conv3 = 0;          // dedicated 8-wave 3x3 kernel: measured 0-12 % SLOWER than the generic 4-wave tiles in an in-process A/B
+                                // (tests/tools/bench_conv.py), so it is off; PCV_AMD_CONV3=1 / pcv_set_tuning("conv3") enables it
     int force_conv3_cfg = -1;   // PCV_AMD_CONV3_CFG: tuning only
+    int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
 
@@ -265,8 +267,8 @@ static int enable_big_lds(pcv_ctx* ctx) {
 enum Conv3Cfg { C3_128x256 = 0, C3_64x512 = 1, C3_COUNT = 2 };
 struct Conv3Info { int BM, BP, threads, lds; };
 static const Conv3Info kConv3[C3_COUNT] = {
-    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 8) * 128},
-    {64, 512, 512, 3 * 64 * 128 + 2 * (512 + 8) * 128},
+    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 8) * 128 + 128},
+    {64, 512, 512, 3 * 64 * 128 + 2 * (512 + 8) * 128 + 128},
 };
 typedef void (*conv3_fn)(const Conv3Params);
 template <int DT> static conv3_fn conv3_for(int cfg) {
@@ -351,6 +353,7 @@ int pcv_create(pcv_ctx** out, int device) {
     if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_CONV3")) ctx->use_conv3 = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_CONV3_CFG")) ctx->force_conv3_cfg = std::atoi(e);
+    if (const char* e = std::getenv("PCV_AMD_C3FLAGS")) ctx->conv3_flags = std::atoi(e);
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc != PCV_OK) {
@@ -361,6 +364,20 @@ int pcv_create(pcv_ctx** out, int device) {
     }
     (void)hipSetDevice(prev);
     *out = ctx;
+    return PCV_OK;
+}
+
+// Tuning/debug switches (same keys as the PCV_AMD_* environment variables read by pcv_create); not part of the
+// reference-facing contract. Returns PCV_ERR_INVALID for an unknown key.
+int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return PCV_ERR_INVALID;
+    const std::string k(key);
+    if (k == "persist") ctx->persist_mode = value;
+    else if (k == "persist_nk") ctx->persist_max_nk = value;
+    else if (k == "conv3") ctx->use_conv3 = value;
+    else if (k == "conv3_cfg") ctx->force_conv3_cfg = value;
+    else if (k == "c3flags") ctx->conv3_flags = value;
+    else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
 }
 
@@ -538,6 +555,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         q.CS = d->Cin / (8 * P.CE);
         q.Kpad = P.Kpad;
         q.act = d->act; q.post_act = d->post_act;
+        q.flags = ctx->conv3_flags;
         int cfg = d->Cout <= 64 ? C3_64x512 : C3_128x256;
         if (ctx->force_conv3_cfg >= 0 && ctx->force_conv3_cfg < C3_COUNT) cfg = ctx->force_conv3_cfg;
         const Conv3Info& T3 = kConv3[cfg];

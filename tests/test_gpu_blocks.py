@@ -121,9 +121,10 @@ _CONV3_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("use_conv3", [False, True], ids=["generic", "conv3x3_kernel"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
-def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, cuda_device):
+def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv3x3_block
@@ -133,6 +134,9 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, cuda_device):
     sd = util.synth_state_dict(blk.state_dict(), seed=77)
     blk.load_state_dict(sd)
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    from pytorchcv_amd import _lib
+    ctx = _lib.ctx_for(0)
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 1 if use_conv3 else 0), ctx)
     x = util.synth_input(N, C, H, W, seed=21)
     res = util.synth_input(N, Cout, H, W, seed=22) if use_res else None
     with torch.no_grad():
@@ -143,6 +147,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, cuda_device):
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None,
                             post_act="relu" if use_res else None)
     d = (y - ref).abs()
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 0), ctx)
     if dtype == "fp32":
         assert float(d.max()) <= 1e-3
     else:
