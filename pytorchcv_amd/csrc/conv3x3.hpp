@@ -54,7 +54,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // (vmcnt(N): everything older than the N youngest VMEM ops of this wave has landed; ops issued later - epilogue
 // stores - only make the wait stricter.) "g+1" of a tile's last group is group 0 of the block's next tile.
 template <int DT, int WC, int WP>
-__global__ __launch_bounds__(64 * WC * WP) void conv3x3_kernel(const Conv3Params p) {
+__global__ __launch_bounds__(64 * WC * WP, 2) void conv3x3_kernel(const Conv3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int CB = 4, PB = 4, NPAIR = 2;
     constexpr int NW = WC * WP;

@@ -111,7 +111,7 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 // FAST: both activations are none/relu/relu6 (a clamp); the general activation codes live in the FAST=false build so
 // that their transcendental code does not bloat the hot kernel.
 template <int DT, int KS, int S, bool FAST>
-__global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
+__global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = Elem<DT>::BYTES;
     constexpr int KEEP = KS > S ? KS - S : 0;       // rows shared by consecutive output rows

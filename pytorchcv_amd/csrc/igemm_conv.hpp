@@ -36,6 +36,7 @@ struct IgemmParams {
     const float* shift;
     uint32_t x_bytes;       // buffer num_records for x
     uint32_t w_bytes;       // buffer num_records for w
+    uint32_t y_bytes;       // buffer num_records for y (16-bit non-ragged outputs are written with range-checked stores)
     int M;                  // N*Ho*Wo
     int Cout;               // valid output channels per group-block (== Cout_total when gridDim.y == 1)
     int Cout_total;         // channel pitch of y / residual
@@ -58,6 +59,7 @@ struct IgemmParams {
     int Cin;                // input channels per group-block (KHW == 1: chunks beyond it are zero-filled)
     int ksteps_per_tap;     // KHW == 9: K-steps per filter tap (= cin_blk / elements per K-step)
     int korder;             // KHW == 9: 0 = K ordered (r, q, slice), 1 = (r, slice, q)
+    int wstat;              // weight-stationary persistent mode (nk == 1, one channel tile, one group-block)
 };
 
 template <int DT> struct Mma;
@@ -96,7 +98,7 @@ template <> struct Mma<PCV_F32> {
 // LDS-DMA loads of the next tile's first K-step are issued before this tile's last MFMAs and epilogue. The residual
 // tile and scale/shift are fetched to registers BEFORE the last K-step's MFMAs so their latency hides under them.
 template <int DT, int OT, int CB, int PB, int WC, int WP, bool RAGGED, int KHW>
-__global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const IgemmParams p) {   // 2 waves per SIMD = 2 blocks per CU: caps VGPR+AGPR at 256
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (buffer-resource types are device-only)
     constexpr int NW = WC * WP;
     constexpr int BM = 16 * CB * WC;          // channel rows per block tile
@@ -178,6 +180,13 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // 16-bit non-ragged outputs are written with range-checked buffer stores: one store instruction per (ip, j) for every
+    // wave, no branches in the epilogue (tile tails / channel padding get an offset beyond num_records and are dropped).
+    // (Leaving those stores in flight across the next barrier with a counted vmcnt was measured: no gain, removed.)
+    constexpr bool FAST_STORE = !RAGGED && OT != PCV_F32;
+
     // issue the LDS-DMA loads of K-step k of tile state S into stage `buf`
     // KHW == 0: the K-chunk descriptor of a step is fetched one step ahead (`kd_next`), so that its global-load latency
     // hides under the previous step's MFMAs instead of stalling - and draining - the DMA issue.
@@ -185,12 +194,20 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
         return *reinterpret_cast<const u32x2*>(p.ktab + 2 * (k * 8 + cs));
     };
     u32x2 kd_next = {0u, 0u};
+    // Weight-stationary mode (host sets p.wstat when a tile has ONE K-step and ONE channel tile covers all outputs,
+    // i.e. every tile of this block uses the same 128-byte-per-row weight slab): the slab is loaded once into stage 0's
+    // weight rows and only the activation rows are streamed afterwards - the HBM-bound 1x1 layers with Cin <= 64.
+    const bool wstat = (KHW == 1) && p.wstat != 0;      // compile-time false for the 3x3 / table-driven instantiations
+    bool w_loaded = false;
     auto stage = [&](const TileState& S, int k, int buf) {
         char* sbase = smem + buf * STAGE;
+        if (!(wstat && w_loaded)) {
 #pragma unroll
-        for (int i = 0; i < WLOADS; ++i) {
-            char* dst = sbase + (8 * (i * NW + wave)) * 128;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, PCV_LDS(dst), 16, S.woff[i], k * 128, 0, 0);
+            for (int i = 0; i < WLOADS; ++i) {
+                char* dst = sbase + (8 * (i * NW + wave)) * 128;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, PCV_LDS(dst), 16, S.woff[i], k * 128, 0, 0);
+            }
+            w_loaded = true;
         }
         int koff;
         uint32_t r, q;
@@ -247,12 +264,13 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
     };
     auto compute = [&](int buf) {
         const char* sbase = smem + buf * STAGE;
+        const char* wsbase = wstat ? smem : sbase;       // weight-stationary: the slab lives in stage 0
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int swz = kk == 0 ? swz0 : swz1;
             frag a[CB], b[PB];
 #pragma unroll
-            for (int i = 0; i < CB; ++i) a[i] = *reinterpret_cast<const frag*>(sbase + wfrag + i * 2048 + swz);
+            for (int i = 0; i < CB; ++i) a[i] = *reinterpret_cast<const frag*>(wsbase + wfrag + i * 2048 + swz);
 #pragma unroll
             for (int j = 0; j < PB; ++j) b[j] = *reinterpret_cast<const frag*>(sbase + xfrag + j * 2048 + swz);
 #pragma unroll
@@ -286,8 +304,6 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
         const bool has_next = ntile < tend;
         if (has_next) setup(ntile, nxt);       // address math overlaps the DMA wait
         __syncthreads();
-        if (has_next) stage(nxt, 0, buf ^ 1);
-        if constexpr (KHW == 0) kd_next = load_kdesc(nk > 1 ? 1 : 0);
 
         // Packed weight row (16*i + rho) of a 64-row group holds channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3), so
         // lane group fq owns the 8 consecutive channels 32*ip + 8*fq .. +7 (accumulators 2ip and 2ip+1).
@@ -333,13 +349,20 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
             }
         }
 
+        // the next tile's first K-step is requested AFTER the epilogue operands, so that waiting for those (the compiler
+        // counts VMEM ops in issue order) does not also wait for this DMA
+        if (has_next) stage(nxt, 0, buf ^ 1);
+        if constexpr (KHW == 0) kd_next = load_kdesc(nk > 1 ? 1 : 0);
+
         compute(buf);
 
         // ---- epilogue: scale/shift -> act -> (+residual) -> post_act -> NHWC store ----------------------------
 #pragma unroll
         for (int ip = 0; ip < NPAIR; ++ip) {
             const int ch0 = chBlk + 32 * ip + 8 * fq;           // within the group-block
-            if (ch0 >= p.Cout) continue;
+            if constexpr (!FAST_STORE) {
+                if (ch0 >= p.Cout) continue;
+            }
             const int chg = chGlob0 + ch0;                      // global channel
             if constexpr (RAGGED) {
 #pragma unroll
@@ -352,7 +375,9 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
                 const int m = mBase + 16 * j;
-                if (m >= p.M) continue;
+                if constexpr (!FAST_STORE) {
+                    if (m >= p.M) continue;
+                }
                 const size_t eoff = (size_t)m * p.Cout_total + chg;
                 float v[8];
 #pragma unroll
@@ -392,7 +417,11 @@ __global__ __launch_bounds__(64 * WC * WP) void igemm_conv_kernel(const IgemmPar
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = pack2<OT>(v[2 * e], v[2 * e + 1]);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.y) + eoff) = o;
+                    // exactly one store instruction per (ip, j) for every wave: out-of-range pieces (tile tail, channel
+                    // padding) get an offset beyond num_records and are dropped by the range check
+                    const bool ok = ch0 < p.Cout && m < p.M;
+                    const uint32_t boff = ok ? (uint32_t)(eoff * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
                 }
             }
         }

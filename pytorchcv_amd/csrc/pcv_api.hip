@@ -29,6 +29,8 @@ struct pcv_ctx {
                                 // (tests/tools/bench_conv.py), so it is off; PCV_AMD_CONV3=1 / pcv_set_tuning("conv3") enables it
     int force_conv3_cfg = -1;   // PCV_AMD_CONV3_CFG: tuning only
     int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
+    int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
+    int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
 
@@ -377,6 +379,8 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "conv3") ctx->use_conv3 = value;
     else if (k == "conv3_cfg") ctx->force_conv3_cfg = value;
     else if (k == "c3flags") ctx->conv3_flags = value;
+    else if (k == "tile") ctx->force_tile = value;
+    else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
 }
@@ -578,6 +582,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     else if (P.cout_blk <= 128) tile = TILE_C128;
     else if (P.cout_blk <= 256) tile = (d->kh * d->kw > 1) ? TILE_C128 : TILE_C256;   // 256x64 only pays for HBM-bound 1x1 (reads x once)
     else tile = TILE_C128;
+    if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !ragged && d->out_dtype == d->dtype) tile = ctx->force_tile;
     if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
     const bool special = ragged || d->out_dtype != d->dtype;
     int khw = 0;
@@ -599,6 +604,12 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     p.shift = shift;
     p.x_bytes = (uint32_t)xbytes;
     p.w_bytes = (uint32_t)P.w_bytes;
+    {
+        const unsigned long long ybytes = M64 * (unsigned long long)d->Cout * esize(d->out_dtype);
+        if (ybytes >= 0x80000000ull && d->out_dtype != PCV_F32)
+            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+        p.y_bytes = ybytes >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ybytes;
+    }
     p.M = (int)M64;
     p.Cout = P.cout_blk;
     p.Cout_total = d->Cout;
@@ -642,6 +653,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     if (nblocks > nTiles) nblocks = nTiles;
     nblocks = (nblocks + 7) / 8 * 8;
     dim3 grid((unsigned)nblocks);
+    p.wstat = (ctx->use_wstat && persistent && P.nk == 1 && p.nChTiles == 1 && P.ngb == 1) ? 1 : 0;
     hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
