@@ -90,6 +90,21 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const PackParams p) {
     store_elem<DT>(p.out, (size_t)i, v);
 }
 
+// stem (stem_conv.hpp): w fp32 [Cout, Cin<=4, kh, kw] -> [kh][64 rows in MFMA order][8 pixels x 4 channels];
+// window pixel `pix` of an output column is filter tap q = pix - qshift (qshift = pad_l & 1), anything else is zero.
+template <int DT>
+__global__ __launch_bounds__(256) void pack_stem_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin,
+                                                       int kh, int kw, int qshift) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kh * 64 * 32) return;
+    const int k = i & 31, pos = (i >> 5) & 63, r = i >> 11;
+    const int ch = 32 * (pos >> 5) + 8 * ((pos & 15) >> 2) + 4 * ((pos >> 4) & 1) + (pos & 3);
+    const int pix = k >> 2, c = k & 3, q = pix - qshift;
+    float v = 0.f;
+    if (ch < Cout && c < Cin && q >= 0 && q < kw) v = w[(((size_t)ch * Cin + c) * kh + r) * kw + q];
+    store_elem<DT>(out, (size_t)i, v);
+}
+
 // depthwise: w fp32 [C,1,kh,kw] -> [kh*kw][C]
 template <int DT>
 __global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ w, void* __restrict__ out, int C, int khkw) {

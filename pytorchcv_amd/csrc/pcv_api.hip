@@ -9,6 +9,7 @@
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "conv3x3_inst.hpp"
+#include "stem_conv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 
@@ -56,6 +57,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // Convolution plan: everything that depends on the descriptor but not on the data pointers.
 // ---------------------------------------------------------------------------------------------------------
 struct ConvPlan {
+    bool stem = false;        // dedicated stem kernel (stem_conv.hpp): blob = [kh][64][32] weights, no K-chunk table
     bool conv3 = false;       // dedicated 3x3/s1/p1 kernel: K ordered (filter row, 128-byte channel slice, filter column)
     int ES = 2, CE = 8;
     bool pair = false;        // stem scheme: x_cpitch == 4 at 16 bit, one chunk = two pixels x 4 channels
@@ -106,6 +108,9 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
               d.pad_t == 1 && d.pad_l == 1 && d.pad_b == 1 && d.pad_r == 1 && d.Cin % (8 * P.CE) == 0 && cpitch == d.Cin &&
               (d.x_wpitch <= 0 || d.x_wpitch == d.W) && d.out_dtype == d.dtype && d.Cout % 8 == 0;
 
+    P.stem = P.pair && d.stride_h == 2 && d.stride_w == 2 && d.dil_h == 1 && d.Cout <= 64 && d.Cout % 8 == 0 && d.kh <= 7 &&
+             d.kw + (d.pad_l & 1) <= 8 && d.out_dtype == d.dtype;
+
     // taps
     if (P.pair) {
         if (d.stride_w % 2 != 0 || d.dil_w != 1) return "padded 4-channel stem needs even stride_w and dilation 1";
@@ -136,6 +141,11 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
     P.total_bytes = P.ktab_bytes + P.w_bytes;
     if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
 
+    if (P.stem) {
+        P.ktab_bytes = 0;
+        P.w_bytes = (size_t)d.kh * 64 * 32 * P.ES;
+        P.total_bytes = P.w_bytes;
+    }
     P.Ho = (d.H + d.pad_t + d.pad_b - d.dil_h * (d.kh - 1) - 1) / d.stride_h + 1;
     P.Wo = (d.W + d.pad_l + d.pad_r - d.dil_w * (d.kw - 1) - 1) / d.stride_w + 1;
 
@@ -298,6 +308,21 @@ static int enable_conv3(pcv_ctx* ctx) {
     return PCV_OK;
 }
 
+// ---- stem kernel ------------------------------------------------------------------------------------------------------
+static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16;
+static int g_stem_blocks_per_cu[2];
+static int enable_stem(pcv_ctx* ctx) {
+    const void* fns[2] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16>),
+                          reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16>)};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
+        int nb = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, kStemLds));
+        g_stem_blocks_per_cu[i] = nb < 1 ? 1 : nb;
+    }
+    return PCV_OK;
+}
+
 // launch helpers (templates need C++ linkage)
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
@@ -358,6 +383,7 @@ int pcv_create(pcv_ctx** out, int device) {
     if (const char* e = std::getenv("PCV_AMD_C3FLAGS")) ctx->conv3_flags = std::atoi(e);
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_conv3(ctx);
+    if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
         delete ctx;
@@ -439,6 +465,13 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
     const char* why = plan_conv(*d, P, true);
     if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv_pack: ") + why);
     hipStream_t s = (hipStream_t)stream;
+    if (P.stem) {
+        const int total = d->kh * 64 * 32;
+        if (d->dtype == PCV_BF16) pack_stem_kernel<PCV_BF16><<<(total + 255) / 256, 256, 0, s>>>(w, packed, d->Cout, d->Cin, d->kh, d->kw, d->pad_l & 1);
+        else pack_stem_kernel<PCV_F16><<<(total + 255) / 256, 256, 0, s>>>(w, packed, d->Cout, d->Cin, d->kh, d->kw, d->pad_l & 1);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
     // load-time only: synchronous uploads of the two small host-built tables
     uint32_t* ksrc_dev = nullptr;
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -540,6 +573,32 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     if (!aligned16(x) || !aligned16(packed) || !aligned16(y) || (residual && !aligned16(residual)) ||
         (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
+
+    if (P.stem) {
+        StemParams q;
+        q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
+        const unsigned long long ybytes = M64 * (unsigned long long)d->Cout * P.ES;
+        if (ybytes >= 0x80000000ull)
+            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+        q.y_bytes = (uint32_t)ybytes;
+        q.N = d->N; q.H = d->H; q.W = d->W; q.Wp = wpitch; q.Ho = P.Ho; q.Wo = P.Wo; q.Cout = d->Cout;
+        q.kh = d->kh; q.pt = d->pad_t; q.x0off = -(d->pad_l + (d->pad_l & 1));
+        q.tilesH = (P.Ho + 15) / 16; q.tilesW = (P.Wo + 15) / 16;
+        const long long nT = (long long)d->N * q.tilesH * q.tilesW;
+        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+        q.nTiles = (int)nT;
+        q.act = d->act;
+        if (d->has_residual || d->post_act != PCV_ACT_NONE)
+            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel has no residual / post-activation path");
+        long long nb = (long long)ctx->num_cu * g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1];
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        if (d->dtype == PCV_BF16) hipLaunchKernelGGL(stem_conv_kernel<PCV_BF16>, dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(stem_conv_kernel<PCV_F16>, dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
 
     bool take_conv3 = P.conv3 && ctx->use_conv3;
     if (take_conv3 && ctx->force_conv3_cfg < 0) {

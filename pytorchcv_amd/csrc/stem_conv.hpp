@@ -1,0 +1,177 @@
+// stem_conv.hpp - first convolution of the nets (Cin <= 4, stride 2): ResNet's 7x7/2 pad 3 (reference resnet.py:250-254) and
+// MobileNetV2's 3x3/2 pad 1 init block (mobilenetv2.py:109-113), 16-bit storage, Cout <= 64, fused BN + activation.
+//
+// The generic implicit GEMM gathers this layer's operand in 16-byte pieces straight from L2 (K = 49 taps x 4 padded
+// channels, every input pixel is fetched ~12 times): 1.6 GB of L2->LDS gather traffic for ResNet-50 at batch 256.
+// Here the input window of a 16x16 output tile (a 37x40-pixel patch of the zero-padded NHWC4 image, 12 KB) is staged
+// in LDS ONCE with coalesced row-contiguous LDS-DMA, and the MFMA B fragments are read from that patch directly:
+// for output column `fr` and filter row r, lane group fq needs the 16 bytes (= 2 pixels x 4 channels) at patch pixel
+// 2*fr + 2*fq of patch row 2*orow + r - consecutive lanes read consecutive 16-byte slots, so the overlapping windows
+// cost nothing. One filter row = one K=32 MFMA step (8 pixels x 4 channels; the leading pad pixel and channel 3 carry
+// zero weights). The weights (Cout x kh x 32, <= 28 KB) stay resident in LDS for the whole persistent block.
+#pragma once
+#include "pcv_common.hpp"
+#include "igemm_conv.hpp"     // Mma<DT>
+
+struct StemParams {
+    const void* x;            // NHWC4 [N, H, Wp, 4], Wp even, pad column/channel zero
+    const void* w;            // packed [kh][64 rows (MFMA order)][32]  (K element = pixel*4 + channel)
+    void* y;                  // NHWC [N, Ho, Wo, Cout]
+    const float* scale;
+    const float* shift;
+    uint32_t x_bytes, w_bytes, y_bytes;
+    int N, H, W, Wp, Ho, Wo, Cout;
+    int kh;                   // filter rows (kw is folded into the 8-pixel window: kw <= 7)
+    int pt;                   // top padding
+    int x0off;                // patch column origin relative to 2*wo0 (= -(pl + (pl & 1)))
+    int tilesH, tilesW, nTiles;
+    int act;
+};
+
+// 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 64 (padded) channels.
+template <int DT>
+__global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TH = 16, TW = 16;
+    constexpr int PCH = 20;                      // 16-byte chunks (pixel pairs) per patch row: 2*15 + 2*3 + 2 -> 20
+    constexpr int PRMAX = 2 * (TH - 1) + 7;      // 37 patch rows for kh = 7
+    constexpr int PCHUNKS = 768;                 // 3 DMA instructions per thread (>= PRMAX * PCH = 740)
+    constexpr int WBYTES = 7 * 64 * 64;          // weights: up to 7 filter rows x 64 rows x 64 B
+    constexpr int PBYTES = PCHUNKS * 16;
+    typedef typename Mma<DT>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights | patch 0 | patch 1]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int PR = 2 * (TH - 1) + p.kh;
+
+    const int perXcd = (p.nTiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int tstride = gridDim.x >> 3;
+    int tile = xcd * perXcd + (int)(blockIdx.x >> 3);
+    const int tend = min(p.nTiles, (xcd + 1) * perXcd);
+    if (tile >= tend) return;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+
+    // ---- weights: loaded once. LDS row (r, ch) is 64 B = 4 chunks; chunk slot s holds K-chunk s ^ f(ch) with
+    //      f = [0,2,3,1][(ch >> 2) & 3], which makes the 16-lane ds_read_b128 groups conflict-free on 64-byte rows.
+    {
+        const int nchunks = p.kh * 64 * 4;
+        for (int c = tid; c < (nchunks + 255) / 256 * 256; c += 256) {
+            const int row = c >> 2, slot = c & 3;
+            const int f = (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+            const uint32_t off = c < nchunks ? (uint32_t)((row * 4 + (slot ^ f)) * 16) : 0x80000000u;
+            char* dst = smem + (c & ~63) * 16;                                   // wave-uniform: 64 consecutive chunks
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, PCV_LDS(dst), 16, off, 0, 0, 0);
+        }
+    }
+
+    // ---- patch DMA: chunk c = 256*j + tid -> patch row c / PCH, pixel pair c % PCH (tile independent) ------------------
+    int prow[3], pcol[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = 256 * j + tid;
+        prow[j] = c / PCH;
+        pcol[j] = c - prow[j] * PCH;
+    }
+    auto issue_patch = [&](int t, int buf) {
+        const int tw = t % p.tilesW;
+        const int t2 = t / p.tilesW;
+        const int th = t2 % p.tilesH;
+        const int n = t2 / p.tilesH;
+        const int hi0 = th * TH * 2 - p.pt;
+        const int wp0 = tw * TW * 2 + p.x0off;                   // even
+        char* dst0 = smem + WBYTES + buf * PBYTES;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int hi = hi0 + prow[j];
+            const int wp = wp0 + 2 * pcol[j];
+            const bool ok = prow[j] < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wp < (unsigned)p.Wp;
+            const uint32_t off = ok ? (uint32_t)((((n * p.H + hi) * p.Wp + wp)) * 8) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(dst0 + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------
+    const int wf = (0x78 >> (2 * ((fr >> 2) & 3))) & 3;
+    const int wfrag = fr * 64 + ((fq ^ wf) << 4);                // + r*4096 + i*1024
+    const int xfrag = (fr + fq) * 16;                            // + (2*orow + r) * PCH*16
+
+    float sc[2][8], sf[2][8];
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {
+        const int ch0 = 32 * ip + 8 * fq;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = ch0 + e < p.Cout;
+            sc[ip][e] = ok ? (p.scale ? p.scale[ch0 + e] : 1.f) : 0.f;
+            sf[ip][e] = ok ? (p.shift ? p.shift[ch0 + e] : 0.f) : 0.f;
+        }
+    }
+    const ActClamp act = make_act(p.act);
+
+    issue_patch(tile, 0);
+    int buf = 0;
+    while (true) {
+        const int ntile = tile + tstride;
+        const bool has_next = ntile < tend;
+        __syncthreads();                                         // weights + this tile's patch landed; other buffer free
+        if (has_next) issue_patch(ntile, buf ^ 1);
+
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* pbase = smem + WBYTES + buf * PBYTES + xfrag;
+        for (int r = 0; r < p.kh; ++r) {
+            frag a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const frag*>(smem + r * 4096 + i * 1024 + wfrag);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const frag*>(pbase + (2 * (4 * wave + j) + r) * (PCH * 16));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
+        }
+
+        // ---- epilogue: BN + activation, 16-byte NHWC stores (range-checked: tile tails and channel padding drop) ------------
+        const int tw = tile % p.tilesW;
+        const int t2 = tile / p.tilesW;
+        const int th = t2 % p.tilesH;
+        const int n = t2 / p.tilesH;
+        const int wo = tw * TW + fr;
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            const int ch0 = 32 * ip + 8 * fq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ho = th * TH + 4 * wave + j;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
+                    v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
+                }
+                apply_act8(v, act);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                const bool ok = ch0 < p.Cout && ho < p.Ho && wo < p.Wo;
+                const uint32_t boff = ok ? (uint32_t)(((((n * p.Ho + ho) * p.Wo + wo)) * p.Cout + ch0) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
+            }
+        }
+        if (!has_next) break;
+        tile = ntile;
+        buf ^= 1;
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}

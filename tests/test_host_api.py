@@ -65,7 +65,10 @@ def test_packed_size_planning_is_pure_host_logic():
     d = _desc(Cin=3, Cout=64, kh=7, kw=7, stride_h=2, stride_w=2, pad_t=3, pad_l=3, pad_b=3, pad_r=3, x_cpitch=4, H=32, W=32,
               x_wpitch=32)
     assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
-    assert n.value == 256 + 64 * 256 * 2
+    assert n.value == 7 * 64 * 32 * 2            # Cout <= 64: dedicated stem kernel, blob = [kh][64][8 pixels x 4 channels]
+    d.Cout = 128                                 # wider stems stay on the implicit GEMM with the pixel-pair K-chunk table
+    assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    assert n.value == 256 + 128 * 256 * 2
     # grouped g=32, 4 channels per group -> 4 group blocks of 32 channels, K = 9*32 = 288 -> 5 K-steps (320)
     d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128)
     assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
