@@ -118,13 +118,13 @@ def cpu_baseline(model, sd_cpu, budget_s=20.0):
     from pytorchcv_amd.synth import synth_input
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    bs = 16
+    bs = 32
     x = synth_input(bs, seed=11)
     t0 = time.time()
     refnet.forward(model, sd_cpu, x[:2])                      # warm-up (thread pool, oneDNN primitives)
     iters, elapsed = 0, 0.0
     t_start = time.time()
-    while iters < 1 or (time.time() - t_start < budget_s * 0.5 and iters < 8):
+    while iters < 2 or (time.time() - t_start < budget_s and iters < 64):
         t1 = time.time()
         refnet.forward(model, sd_cpu, x)
         elapsed += time.time() - t1
