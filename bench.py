@@ -155,8 +155,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PCV_BENCH_FORCE_DIST") == "1"    # (forcing it at world size 1 rehearses the RCCL calls)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import pytorchcv_amd
@@ -173,7 +177,7 @@ def main():
         sd_cpu = synth_state_dict(net.state_dict(), seed=1234, calib=calib_for(model))
         net.load_state_dict(sd_cpu, strict=True)
     net = pytorchcv_amd.set_compute_dtype(net.to(dev), args.dtype)
-    if world > 1:
+    if use_dist:
         broadcast_module_state(net, src=0)           # RCCL broadcast of rank 0's weights over xGMI
 
     # synthetic N(0,1)-like images: 8 distinct seeded images tiled to the batch (performance is data independent)
@@ -183,22 +187,22 @@ def main():
 
     def step():
         y = runner.run_local(x)
-        return runner.gather(y) if world > 1 else y
+        return runner.gather_all(y) if use_dist else y
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -250,7 +254,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

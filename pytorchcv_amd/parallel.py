@@ -67,6 +67,12 @@ class ShardedInference(object):
         with torch.no_grad():
             return self.forward_fn(x_local)
 
+    def gather_all(self, y_local: torch.Tensor) -> torch.Tensor:
+        """Equal shards: one all-gather collective, issued even at world size 1 (so that a single-GPU rehearsal runs RCCL)."""
+        out = torch.empty((self.world * y_local.shape[0],) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+        dist.all_gather_into_tensor(out, y_local.contiguous(), group=self.group)
+        return out
+
     def gather(self, y_local: torch.Tensor, global_batch: int | None = None) -> torch.Tensor:
         """All ranks receive the logits of the whole batch, in image order."""
         if self.world == 1:
