@@ -48,6 +48,18 @@ static int fail(pcv_ctx* ctx, int code, const std::string& msg) {
             return fail(ctx, PCV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
     } while (0)
 
+// Launches go to the context's device whatever the caller's current device is (restored on return).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int esize(int dt) { return dt == PCV_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == PCV_F32 || dt == PCV_BF16 || dt == PCV_F16; }
@@ -420,6 +432,7 @@ int pcv_destroy(pcv_ctx* ctx) {
 int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H, int W, int cpitch, int wpitch,
                      int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpitch < C || wpitch < W || !dtype_ok(dtype))
         return fail(ctx, PCV_ERR_INVALID, "pcv_nchw_to_nhwc: bad argument");
     if (!(cpitch == 4 || cpitch % 8 == 0) && !(dtype == PCV_F32 && cpitch % 4 == 0))
@@ -436,6 +449,7 @@ int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H,
 
 int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || !dtype_ok(dtype))
         return fail(ctx, PCV_ERR_INVALID, "pcv_nhwc_to_nchw: bad argument");
     const long total = (long)N * C * H * W;
@@ -459,6 +473,7 @@ int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes) {
 
 int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!d || !w || !packed) return fail(ctx, PCV_ERR_INVALID, "pcv_conv_pack: NULL argument");
     if (!aligned16(packed)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv_pack: packed buffer must be 16-byte aligned");
     ConvPlan P;
@@ -526,6 +541,7 @@ int pcv_dwconv_packed_bytes(const pcv_conv_desc* d, size_t* bytes) {
 
 int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!d || !w || !packed) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv_pack: NULL argument");
     const char* why = check_dw(*d);
     if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_dwconv_pack: ") + why);
@@ -542,6 +558,7 @@ int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* 
 int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, const float* mean, const float* var,
                 float eps, const float* conv_bias, float* scale, float* shift, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (C <= 0 || !scale || !shift) return fail(ctx, PCV_ERR_INVALID, "pcv_bn_fold: bad argument");
     const bool any = gamma || beta || mean || var;
     const bool all = gamma && beta && mean && var;
@@ -555,6 +572,7 @@ int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, cons
 int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
                      const float* shift, const void* residual, void* y, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
     if (d->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: has_residual but residual is NULL");
     if (d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty input");
@@ -721,6 +739,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
                        const float* shift, const void* residual, void* y, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!d || !x || !packed || !y || !scale || !shift) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: NULL argument");
     const char* why = check_dw(*d);
     if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_dwconv2d_fused: ") + why);
@@ -770,6 +789,7 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
 int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p, int dtype,
                   void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || p < 0 || !dtype_ok(dtype) || C % 8 != 0 ||
         2 * p > k)
         return fail(ctx, PCV_ERR_INVALID, "pcv_maxpool2d: bad argument (C must be a multiple of 8, pad <= k/2)");
@@ -788,6 +808,7 @@ int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int
 int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int dtype,
                   int out_dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || !dtype_ok(dtype) || C % 8 != 0 ||
         (out_dtype != dtype && out_dtype != PCV_F32) || k > H || k > W)
         return fail(ctx, PCV_ERR_INVALID, "pcv_avgpool2d: bad argument (C must be a multiple of 8, k <= H,W)");
@@ -809,6 +830,7 @@ int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int
 int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* bias, void* y, int N, int Cin,
                   int Cout, int dtype, int out_dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     pcv_conv_desc d;
     std::memset(&d, 0, sizeof(d));
     d.N = N; d.H = 1; d.W = 1; d.Cin = Cin; d.Cout = Cout; d.kh = 1; d.kw = 1;
@@ -820,6 +842,7 @@ int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* 
 
 int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int C, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !mean || N <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype))
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_squeeze: bad argument (C must be a multiple of 8)");
     hipStream_t st = (hipStream_t)stream;
@@ -833,6 +856,7 @@ int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int 
 int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
                   float* gate, int N, int C, int M, int mid_act, int out_act, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!mean || !w1 || !b1 || !w2 || !b2 || !gate || N <= 0 || C <= 0 || M <= 0)
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: bad argument");
     const size_t lds = (size_t)(C + M) * sizeof(float);
@@ -845,6 +869,7 @@ int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float*
 int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y, int N, int HW, int C,
                  int post_act, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
     if (!x || !gate || !y || N <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype))
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_scale: bad argument (C must be a multiple of 8)");
     const long total8 = (long)N * HW * (C / 8);

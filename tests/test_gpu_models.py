@@ -88,3 +88,28 @@ def test_odd_num_classes_and_in_channels(cuda_device):
     ref = refnet.resnet_forward(sd, x, blocks=18)
     assert y.shape == (2, 10)
     assert float((y - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_batch_split_beyond_2gib_window(cuda_device):
+    """One launch addresses its input through a 32-bit buffer window (< 2 GiB); larger batches are split by the host
+    (PCV_ERR_TOO_LARGE -> ConvRunner._launch_range). The split result equals the per-chunk results bit for bit."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block, dwconv3x3_block
+    N, C, H = 36000, 32, 32                      # 36000*32*32*32*2 B = 2.36 GB > 2 GiB
+    x = torch.empty((N, H, H, C), dtype=torch.bfloat16, device=cuda_device)
+    base = torch.randn((500, H, H, C), device=cuda_device).to(torch.bfloat16)
+    for i in range(0, N, 500):
+        x[i:i + 500] = base
+    xh = engine.NHWC(x, N, H, H, C)
+    for blk in (conv1x1_block(in_channels=C, out_channels=16), dwconv3x3_block(in_channels=C, out_channels=C)):
+        blk = blk.eval()
+        blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=3))
+        blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), "bf16")
+        with torch.no_grad():
+            y = blk(xh).t
+            y_small = blk(engine.NHWC(base, 500, H, H, C)).t
+        assert y.shape[0] == N
+        assert torch.equal(y[:500], y_small) and torch.equal(y[N - 500:], y_small) and torch.equal(y[17500:18000], y_small)
+    del x, y
+    torch.cuda.empty_cache()
