@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -235,6 +235,52 @@ def resnext_forward(sd, x, blocks, cardinality, bottleneck_width, q=None, taps=N
     return _classifier(sd, x, q)
 
 
+def seresnext_forward(sd, x, blocks, cardinality, bottleneck_width, q=None, taps=None):
+    """SEResNeXt.forward / SEResNeXtUnit (reference seresnext.py:17-76,147-151): ResNeXt body + SEBlock before the skip add."""
+    q = q or Quant(None)
+    layers = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}[blocks]
+    channels = [[c] * n for c, n in zip([256, 512, 1024, 2048], layers)]
+    x = q.r(x)
+    x = _res_init_block(sd, x, q)
+    _tap(taps, "init_block", x)
+    in_ch = 64
+    for i, cps in enumerate(channels):
+        for j, out_ch in enumerate(cps):
+            stride = 2 if (j == 0) and (i != 0) else 1
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            if (in_ch != out_ch) or (stride != 1):
+                identity = conv_block(sd, p + "identity_conv.", x, stride=stride, act=None, q=q)
+            else:
+                identity = x
+            y = conv_block(sd, p + "body.conv1.", x, q=q)
+            y = conv_block(sd, p + "body.conv2.", y, stride=stride, padding=1, groups=cardinality, q=q)
+            y = conv_block(sd, p + "body.conv3.", y, act=None, q=q)
+            x = se_block(sd, p + "se.", y, q=q, residual=identity, post_act="relu")
+            in_ch = out_ch
+        _tap(taps, "stage{}".format(i + 1), x)
+    return _classifier(sd, x, q)
+
+
+def mobilenet_forward(sd, x, width_scale=1.0, q=None, taps=None):
+    """MobileNet.forward (reference mobilenet.py:92-96): 3x3/2 stem, depthwise-separable units (DwsConvBlock,
+    common/conv.py:546-618: depthwise ConvBlock then pointwise ConvBlock), AvgPool2d(7), Linear."""
+    q = q or Quant(None)
+    channels = [[32], [64], [128, 128], [256, 256], [512] * 6, [1024, 1024]]
+    if width_scale != 1.0:
+        channels = [[int(c * width_scale) for c in ci] for ci in channels]
+    x = q.r(x)
+    x = conv_block(sd, "features.init_block.", x, stride=2, padding=1, q=q)
+    _tap(taps, "init_block", x)
+    for i, cps in enumerate(channels[1:]):
+        for j, out_ch in enumerate(cps):
+            stride = 2 if (j == 0) and (i != 0) else 1
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            x = conv_block(sd, p + "dw_conv.", x, stride=stride, padding=1, groups=x.shape[1], q=q)
+            x = conv_block(sd, p + "pw_conv.", x, q=q)
+        _tap(taps, "stage{}".format(i + 1), x)
+    return _classifier(sd, x, q)
+
+
 def mobilenetv2_forward(sd, x, width_scale=1.0, q=None, taps=None):
     """MobileNetV2.forward (mobilenetv2.py:152-156); LinearBottleneck (mobilenetv2.py:62-71);
     channel plan of get_mobilenetv2 (mobilenetv2.py:183-203)."""
@@ -293,10 +339,14 @@ MODEL_ARCH = {
     "seresnet18": ("seresnet", dict(blocks=18)),
     "seresnet50": ("seresnet", dict(blocks=50)),
     "seresnet101": ("seresnet", dict(blocks=101)),
+    "seresnext50_32x4d": ("seresnext", dict(blocks=50, cardinality=32, bottleneck_width=4)),
+    "seresnext101_32x4d": ("seresnext", dict(blocks=101, cardinality=32, bottleneck_width=4)),
+    "mobilenet_w1": ("mobilenet", dict(width_scale=1.0)),
+    "mobilenet_wd2": ("mobilenet", dict(width_scale=0.5)),
 }
 
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
-           "seresnet": seresnet_forward}
+           "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

@@ -2,7 +2,7 @@
     `get_model(name, **kwargs)` with the reference's contract (pytorchcv/model_provider.py:1364-1382): case-insensitive
     name, `ValueError("Unsupported model: ...")` for unknown names, kwargs (`pretrained`, `root`, `in_channels`, `in_size`,
     `num_classes`) forwarded to the factory. The registry holds the families whose whole forward runs on the MI355X hot
-    path (ResNet, SE-ResNet, ResNeXt, MobileNetV2).
+    path (ResNet, SE-ResNet, ResNeXt, SE-ResNeXt, MobileNet, MobileNetV2).
 """
 
 __all__ = ['get_model']
@@ -11,9 +11,11 @@ from .models import resnet as _resnet
 from .models import mobilenetv2 as _mobilenetv2
 from .models import resnext as _resnext
 from .models import seresnet as _seresnet
+from .models import seresnext as _seresnext
+from .models import mobilenet as _mobilenet
 
 _models = {}
-for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet):
+for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet):
     for _name in _mod.__all__:
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("get_") and callable(_fn):

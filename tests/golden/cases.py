@@ -4,12 +4,13 @@
     Each case: name, kind (constructor in the reference), kwargs, input shape. Data only.
 """
 
-MODELS = ["resnet18", "resnet50", "mobilenetv2_w1", "resnext101_32x4d", "seresnet50"]
+MODELS = ["resnet18", "resnet50", "mobilenetv2_w1", "resnext101_32x4d", "seresnet50", "seresnext50_32x4d", "mobilenet_w1"]
 
 # known answers from the reference's own asserts (resnet.py:983,988; mobilenetv2.py:436; resnext.py:547;
 # model_metainfos.csv:81) and SURVEY.md section 8a16 (state_dict key counts)
 PARAM_COUNTS = {"resnet18": 11689512, "resnet50": 25557032, "mobilenetv2_w1": 3504960,
-                "resnext101_32x4d": 44177704, "seresnet50": 28088024}
+                "resnext101_32x4d": 44177704, "seresnet50": 28088024, "seresnext50_32x4d": 27559896,
+                "mobilenet_w1": 4231976}
 KEY_COUNTS = {"resnet18": 122, "resnet50": 320, "mobilenetv2_w1": 319, "resnext101_32x4d": 626}
 
 BLOCK_CASES = [

@@ -96,7 +96,8 @@ def images(ids):
 
 def make_model(ref_models, name):
     mod = {"resnet18": "resnet", "resnet50": "resnet", "mobilenetv2_w1": "mobilenetv2",
-           "resnext101_32x4d": "resnext", "seresnet50": "seresnet"}[name]
+           "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
+           "mobilenet_w1": "mobilenet"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 
