@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/debug only)")
+    ap.add_argument("--graph", type=int, default=-1, help="replay the forward from a captured hipGraph (1), eager launches (0), "
+                                                          "default: graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,7 +185,16 @@ def main():
     # synthetic N(0,1)-like images: 8 distinct seeded images tiled to the batch (performance is data independent)
     base = synth_input(8, seed=rank).to(dev)
     x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
-    runner = ShardedInference(net)
+    use_graph = args.graph != 0
+    fwd = net
+    if use_graph:
+        from pytorchcv_amd.graph import capture
+        try:
+            fwd = capture(net, x, own_input=True)    # ~60 kernel launches replayed by one hipGraphLaunch; x is the static input
+        except Exception as e:                       # noqa: BLE001 - same kernels either way; only the launch mechanism differs
+            print("hipGraph capture failed ({}); falling back to eager launches".format(e), file=sys.stderr)
+            use_graph = False
+    runner = ShardedInference(fwd)
 
     def step():
         y = runner.run_local(x)
@@ -213,7 +224,8 @@ def main():
     if rank == 0:
         with LaunchTimer(klass) as lt:
             for _ in range(max(3, min(args.steps, 10))):
-                runner.run_local(x)
+                with torch.no_grad():
+                    net(x)                           # eager: events bracket every launch of the class
         s = lt.summary()
         if s is not None:
             if bound == "mfma":
@@ -249,7 +261,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
             "config": {"workload": args.workload, "model": model, "per_gpu_batch": batch, "global_batch": world * batch,
-                       "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world)},
+                       "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world),
+                       "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -113,3 +113,23 @@ def test_batch_split_beyond_2gib_window(cuda_device):
         assert torch.equal(y[:500], y_small) and torch.equal(y[N - 500:], y_small) and torch.equal(y[17500:18000], y_small)
     del x, y
     torch.cuda.empty_cache()
+
+
+def test_graph_replay_equals_eager(cuda_device):
+    """hipGraph capture of the whole forward: bit-identical to eager, for new input contents too."""
+    from pytorchcv_amd.graph import capture
+    net = _net("resnet18", "bf16", cuda_device)
+    _, ids = util.model_golden("resnet18")
+    x = util.images(ids).to(cuda_device)
+    with torch.no_grad():
+        y_eager = net(x).clone()
+        g = capture(net, x)
+        y_graph = g(x, clone=True)
+        x2 = torch.flip(x, dims=[0])
+        y2_graph = g(x2, clone=True)
+        y2_eager = net(x2)
+    assert torch.equal(y_eager, y_graph)
+    assert torch.equal(y2_eager, y2_graph)
+    assert torch.equal(y2_graph, torch.flip(y_graph, dims=[0]))
+    with pytest.raises(RuntimeError, match="captured for input shape"):
+        g(x[:2])
