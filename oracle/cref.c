@@ -9,7 +9,7 @@
  * Reference lines restated (relative to the reference root):
  *   conv2d        pytorchcv/models/common/conv.py:250-258 (nn.Conv2d incl. groups/dilation), :245-249 (4-tuple pad)
  *   bn_eval       pytorchcv/models/common/norm.py:34-50   (nn.BatchNorm2d, eval)
- *   act           pytorchcv/models/common/activ.py:50-81,117-132 (ReLU, ReLU6, Sigmoid)
+ *   act           pytorchcv/models/common/activ.py:16-81,117-132 (Swish, HSigmoid, HSwish, ReLU, ReLU6, Sigmoid)
  *   maxpool2d     pytorchcv/models/resnet.py:255-258      (MaxPool2d(3, 2, 1))
  *   avgpool2d     pytorchcv/models/resnet.py:316-318      (AvgPool2d(7, 1))
  *   linear        pytorchcv/models/resnet.py:320-322
@@ -68,13 +68,16 @@ int cref_bn_eval(float* x, const float* gamma, const float* beta, const float* m
     return 0;
 }
 
-/* in place; act: 0 none, 1 relu, 2 relu6, 3 sigmoid */
+/* in place; act: 0 none, 1 relu, 2 relu6, 3 sigmoid, 4 swish, 5 hsigmoid, 6 hswish */
 int cref_act(float* x, long n, int act) {
     for (long i = 0; i < n; ++i) {
         float v = x[i];
         if (act == 1) v = v > 0.f ? v : 0.f;
         else if (act == 2) v = v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
         else if (act == 3) v = (float)(1.0 / (1.0 + exp(-(double)v)));
+        else if (act == 4) v = v * (float)(1.0 / (1.0 + exp(-(double)v)));
+        else if (act == 5) { float t = v + 3.f; t = t < 0.f ? 0.f : (t > 6.f ? 6.f : t); v = t / 6.f; }
+        else if (act == 6) { float t = v + 3.f; t = t < 0.f ? 0.f : (t > 6.f ? 6.f : t); v = v * t / 6.f; }
         x[i] = v;
     }
     return 0;

@@ -55,7 +55,7 @@ def conv_block_c(x, w, bias=None, bn=None, eps=1e-5, stride=1, padding=0, dilati
     if bn is not None:
         g, b, m, v = [_f32(t) for t in bn]
         L.cref_bn_eval(_p(y), _p(g), _p(b), _p(m), _p(v), ctypes.c_float(eps), N, O, ctypes.c_long(Ho * Wo))
-    code = {None: 0, "relu": 1, "relu6": 2, "sigmoid": 3}
+    code = {None: 0, "relu": 1, "relu6": 2, "sigmoid": 3, "swish": 4, "hsigmoid": 5, "hswish": 6}
     L.cref_act(_p(y), ctypes.c_long(y.size), code[act])
     if residual is not None:
         r = _f32(residual)

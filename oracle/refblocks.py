@@ -5,7 +5,7 @@
     tests/golden/cases.py) over a state_dict, in reference-exact fp32 mode or quantisation-matched 16-bit mode
     (see oracle/refnet.py). Reference lines: common/conv.py:204-543 (ConvBlock and factories), common/att.py:94-105
     (SEBlock), resnet.py:143-263 (ResUnit, ResInitBlock), mobilenetv2.py:16-71 (LinearBottleneck), resnext.py:17-116
-    (ResNeXtUnit), seresnet.py:17-72 (SEResUnit).
+    (ResNeXtUnit), seresnet.py:17-72 (SEResUnit), mobilenetv3.py:18-93 (MobileNetV3Unit).
 """
 
 __all__ = ['block_forward']
@@ -53,7 +53,20 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
         if kind in _KSIZE or kind == "ConvBlock":
             return _conv_kind(kind, kw, sd, x, q)
         if kind == "SEBlock":
-            return se_block(sd, "", x, q=q)
+            return se_block(sd, "", x, q=q, mid_act=_act_name(kw.get("mid_activation", "relu")),
+                            out_act=_act_name(kw.get("out_activation", "sigmoid"), "sigmoid"))
+        if kind == "MobileNetV3Unit":
+            # mobilenetv3.py:40-93
+            stride, act = kw["stride"], _act_name(kw["activation"])
+            residual = x if (kw["in_channels"] == kw["out_channels"] and stride == 1) else None
+            y = x
+            if kw["exp_channels"] != kw["out_channels"]:
+                y = conv_block(sd, "exp_conv.", y, act=act, q=q)
+            k = 3 if kw["use_kernel3"] else 5
+            y = conv_block(sd, "conv1.", y, stride=stride, padding=k // 2, groups=y.shape[1], act=act, q=q)
+            if kw["use_se"]:
+                y = se_block(sd, "se.", y, q=q, out_act="hsigmoid")
+            return conv_block(sd, "conv2.", y, act=None, q=q, residual=residual)
         if kind == "ResInitBlock":
             y = conv_block(sd, "conv.", x, stride=2, padding=3, q=q)
             return F.max_pool2d(y, kernel_size=3, stride=2, padding=1)

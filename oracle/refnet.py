@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -54,6 +54,13 @@ def _act(x: torch.Tensor, act: str | None) -> torch.Tensor:
         return F.relu6(x)
     if act == "sigmoid":
         return torch.sigmoid(x)
+    # activ.py:16-47: Swish x*sigmoid(x); HSigmoid relu6(x+3)/6; HSwish x*relu6(x+3)/6
+    if act == "swish":
+        return x * torch.sigmoid(x)
+    if act == "hsigmoid":
+        return F.relu6(x + 3.0) / 6.0
+    if act == "hswish":
+        return x * F.relu6(x + 3.0) / 6.0
     raise NotImplementedError(act)
 
 
@@ -107,7 +114,8 @@ def conv_block(sd: dict, prefix: str, x: torch.Tensor, stride=1, padding=0, dila
 
 
 def se_block(sd: dict, prefix: str, x: torch.Tensor, q: Quant | None = None,
-             residual: torch.Tensor | None = None, post_act: str | None = None) -> torch.Tensor:
+             residual: torch.Tensor | None = None, post_act: str | None = None,
+             mid_act: str = "relu", out_act: str = "sigmoid") -> torch.Tensor:
     """
     SEBlock.forward, pytorchcv/models/common/att.py:94-105 (use_conv=True): AdaptiveAvgPool2d(1) ->
     1x1 conv + bias -> ReLU -> 1x1 conv + bias -> Sigmoid -> x * w.  The excitation runs in fp32 on
@@ -116,9 +124,9 @@ def se_block(sd: dict, prefix: str, x: torch.Tensor, q: Quant | None = None,
     q = q or Quant(None)
     w = x.mean(dim=(2, 3), keepdim=True)
     w = F.conv2d(w, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"])
-    w = F.relu(w)
+    w = _act(w, mid_act)
     w = F.conv2d(w, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])
-    w = torch.sigmoid(w)
+    w = _act(w, out_act)           # sigmoid, or hsigmoid in MobileNetV3 (mobilenetv3.py:64-69)
     y = x * w
     if residual is not None:
         y = y + residual
@@ -322,6 +330,48 @@ def mobilenetv2_forward(sd, x, width_scale=1.0, q=None, taps=None):
     return x.view(x.size(0), -1)
 
 
+def mobilenetv3_forward(sd, x, version="large", q=None, taps=None):
+    """MobileNetV3.forward (mobilenetv3.py:277-281), MobileNetV3Unit.forward (:82-93), MobileNetV3FinalBlock (:127-131),
+    MobileNetV3Classifier (:167-174); per-unit activation / stride tables of get_mobilenetv3 (:311-332). Channel counts,
+    kernel sizes, the presence of the expansion conv and of SE are read from the state_dict itself."""
+    q = q or Quant(None)
+    if version == "small":
+        use_relu = [[1], [1, 1], [0, 0, 0, 0, 0], [0, 0, 0]]
+        first_stride = True
+    elif version == "large":
+        use_relu = [[1], [1, 1], [1, 1, 1], [0, 0, 0, 0, 0, 0], [0, 0, 0]]
+        first_stride = False
+    else:
+        raise ValueError(version)
+    x = q.r(x)
+    x = conv_block(sd, "features.init_block.", x, stride=2, padding=1, act="hswish", q=q)
+    _tap(taps, "init_block", x)
+    for i, relu_flags in enumerate(use_relu):
+        for j, relu_flag in enumerate(relu_flags):
+            stride = 2 if (j == 0) and ((i != 0) or first_stride) else 1
+            act = "relu" if relu_flag == 1 else "hswish"
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            out_ch = sd[p + "conv2.conv.weight"].shape[0]
+            residual = x if (x.shape[1] == out_ch and stride == 1) else None
+            y = x
+            if (p + "exp_conv.conv.weight") in sd:
+                y = conv_block(sd, p + "exp_conv.", y, act=act, q=q)
+            wdw = sd[p + "conv1.conv.weight"]
+            k = wdw.shape[-1]
+            y = conv_block(sd, p + "conv1.", y, stride=stride, padding=k // 2, groups=wdw.shape[0], act=act, q=q)
+            if (p + "se.conv1.weight") in sd:
+                y = se_block(sd, p + "se.", y, q=q, out_act="hsigmoid")
+            x = conv_block(sd, p + "conv2.", y, act=None, q=q, residual=residual)
+        _tap(taps, "stage{}".format(i + 1), x)
+    x = conv_block(sd, "features.final_block.conv.", x, act="hswish", q=q)
+    if "features.final_block.se.conv1.weight" in sd:
+        x = se_block(sd, "features.final_block.se.", x, q=q, out_act="hsigmoid")
+    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
+    x = q.r(_act(F.conv2d(x, q.r(sd["output.conv1.weight"].float())), "hswish"))
+    x = F.conv2d(x, q.r(sd["output.conv2.weight"].float()), sd["output.conv2.bias"].float())   # dropout: identity in eval
+    return x.view(x.size(0), -1)
+
+
 MODEL_ARCH = {
     "resnet18": ("resnet", dict(blocks=18)),
     "resnet34": ("resnet", dict(blocks=34)),
@@ -344,9 +394,14 @@ MODEL_ARCH = {
     "mobilenet_w1": ("mobilenet", dict(width_scale=1.0)),
     "mobilenet_wd2": ("mobilenet", dict(width_scale=0.5)),
 }
+for _v in ("small", "large"):
+    for _t in ("w7d20", "wd2", "w3d4", "w1", "w5d4"):
+        MODEL_ARCH["mobilenetv3_{}_{}".format(_v, _t)] = ("mobilenetv3", dict(version=_v))
+
 
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
-           "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward}
+           "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
+           "mobilenetv3": mobilenetv3_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

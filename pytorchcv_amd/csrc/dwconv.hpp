@@ -28,7 +28,7 @@ struct DwParams {
     uint32_t x_bytes;     // buffer num_records of x
     int N, H, W, C, Ho, Wo;
     int pt, pl;
-    int C8;               // C / 8
+    int C8;               // C / channels-per-thread
     int TH;               // output rows per thread
     int nseg;             // ceil(Ho / TH)
     int act, post_act;
@@ -60,33 +60,64 @@ template <int DT> __device__ __forceinline__ void store8(void* base, size_t eidx
     }
 }
 
-// raw 8-channel chunk as it comes from memory: 1 x 16 B (16-bit types) or 2 x 16 B (fp32)
-template <int DT> struct RawChunk { u32x4 q[DT == PCV_F32 ? 2 : 1]; };
+// raw CPT-channel chunk as it comes from memory (CPT = 8: 16 B at 16 bit / 32 B fp32; CPT = 4: 8 B / 16 B)
+template <int DT, int CPT> struct RawChunk { uint32_t q[DT == PCV_F32 ? CPT : CPT / 2]; };
 
-template <int DT> __device__ __forceinline__ void raw_to_f32(const RawChunk<DT>& r, float (&v)[8]) {
-    if constexpr (DT == PCV_F32) {
+template <int DT, int CPT>
+__device__ __forceinline__ void raw_load(const __amdgpu_buffer_rsrc_t& rsrc, uint32_t off, RawChunk<DT, CPT>& r) {
+    constexpr int ND = DT == PCV_F32 ? CPT : CPT / 2;     // dwords
+    if constexpr (ND == 8) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = __uint_as_float(r.q[0][e]); v[4 + e] = __uint_as_float(r.q[1][e]); }
+        for (int e = 0; e < 4; ++e) { r.q[e] = a[e]; r.q[4 + e] = b[e]; }
+    } else if constexpr (ND == 4) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r.q[e] = a[e];
     } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unpack2<DT>(r.q[0][e], v[2 * e], v[2 * e + 1]);
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+        r.q[0] = a[0];
+        r.q[1] = a[1];
     }
 }
 
-// 8 channels as 4 packed pairs: the FMAs below lower to v_pk_fma_f32 (two lanes of fp32 per instruction)
-template <int DT> __device__ __forceinline__ void raw_to_f32x2(const RawChunk<DT>& r, f32x2 (&v)[4]) {
-    if constexpr (DT == PCV_F32) {
-        v[0] = (f32x2){__uint_as_float(r.q[0][0]), __uint_as_float(r.q[0][1])};
-        v[1] = (f32x2){__uint_as_float(r.q[0][2]), __uint_as_float(r.q[0][3])};
-        v[2] = (f32x2){__uint_as_float(r.q[1][0]), __uint_as_float(r.q[1][1])};
-        v[3] = (f32x2){__uint_as_float(r.q[1][2]), __uint_as_float(r.q[1][3])};
-    } else {
+// CPT channels as CPT/2 packed pairs: the FMAs below lower to v_pk_fma_f32 (two lanes of fp32 per instruction)
+template <int DT, int CPT> __device__ __forceinline__ void raw_to_f32x2(const RawChunk<DT, CPT>& r, f32x2 (&v)[CPT / 2]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < CPT / 2; ++e) {
+        if constexpr (DT == PCV_F32) {
+            v[e] = (f32x2){__uint_as_float(r.q[2 * e]), __uint_as_float(r.q[2 * e + 1])};
+        } else {
             float lo, hi;
-            unpack2<DT>(r.q[0][e], lo, hi);
+            unpack2<DT>(r.q[e], lo, hi);
             v[e] = (f32x2){lo, hi};
         }
+    }
+}
+
+// load / store CPT consecutive elements as fp32 (plain pointers: weights, scale/shift, residual, output)
+template <int DT, int CPT> __device__ __forceinline__ void loadn(const void* base, size_t eidx, float (&v)[CPT]) {
+    if constexpr (CPT == 8) {
+        load8<DT>(base, eidx, v);
+    } else if constexpr (DT == PCV_F32) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + eidx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e];
+    } else {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(base) + eidx);
+        unpack2<DT>(r[0], v[0], v[1]);
+        unpack2<DT>(r[1], v[2], v[3]);
+    }
+}
+template <int DT, int CPT> __device__ __forceinline__ void storen(void* base, size_t eidx, const float (&v)[CPT]) {
+    if constexpr (CPT == 8) {
+        store8<DT>(base, eidx, v);
+    } else if constexpr (DT == PCV_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + eidx) = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+        u32x2 o = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(base) + eidx) = o;
     }
 }
 
@@ -110,7 +141,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 // FAST: both activations are none/relu/relu6 (a clamp); the general activation codes live in the FAST=false build so
 // that their transcendental code does not bloat the hot kernel.
-template <int DT, int KS, int S, bool FAST>
+// CPT: channels per thread (8, or 4 for the 5x5 window whose 25 taps x 8 channels would not fit the register file).
+template <int DT, int KS, int S, bool FAST, int CPT = 8>
 __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int ES = Elem<DT>::BYTES;
@@ -124,27 +156,28 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
     t /= p.Wo;
     const int seg = (int)(t % p.nseg);
     const int n = (int)(t / p.nseg);
-    const int c0 = c8 * 8;
+    const int c0 = c8 * CPT;
     const int ho_begin = seg * p.TH;
     const int ho_end = min(p.Ho, ho_begin + p.TH);
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
 
-    f32x2 wgt[KS * KS][4];
+    constexpr int NV = CPT / 2;          // packed fp32 pairs per chunk
+    f32x2 wgt[KS * KS][NV];
 #pragma unroll
     for (int k = 0; k < KS * KS; ++k) {
-        float w8[8];
-        load8<DT>(p.w, (size_t)k * p.C + c0, w8);
+        float w8[CPT];
+        loadn<DT, CPT>(p.w, (size_t)k * p.C + c0, w8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wgt[k][e] = (f32x2){w8[2 * e], w8[2 * e + 1]};
+        for (int e = 0; e < NV; ++e) wgt[k][e] = (f32x2){w8[2 * e], w8[2 * e + 1]};
     }
-    f32x2 sc[4], sf[4];
+    f32x2 sc[NV], sf[NV];
     {
-        float a8[8], b8[8];
-        load8<PCV_F32>(p.scale, c0, a8);
-        load8<PCV_F32>(p.shift, c0, b8);
+        float a8[CPT], b8[CPT];
+        loadn<PCV_F32, CPT>(p.scale, c0, a8);
+        loadn<PCV_F32, CPT>(p.shift, c0, b8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[e] = (f32x2){a8[2 * e], a8[2 * e + 1]}; sf[e] = (f32x2){b8[2 * e], b8[2 * e + 1]}; }
+        for (int e = 0; e < NV; ++e) { sc[e] = (f32x2){a8[2 * e], a8[2 * e + 1]}; sf[e] = (f32x2){b8[2 * e], b8[2 * e + 1]}; }
     }
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
 
@@ -157,26 +190,25 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
     const uint32_t rowbytes = (uint32_t)(p.W * p.C * ES);
     const uint32_t imgoff = (uint32_t)n * (uint32_t)p.H * rowbytes;
 
-    auto fetch_row = [&](int hi, RawChunk<DT> (&row)[KS]) {
+    auto fetch_row = [&](int hi, RawChunk<DT, CPT> (&row)[KS]) {
         const bool rowok = (unsigned)hi < (unsigned)p.H;
         const uint32_t rbase = imgoff + (uint32_t)hi * rowbytes;
 #pragma unroll
         for (int q = 0; q < KS; ++q) {
             const uint32_t off = (rowok && coloff[q] != 0x80000000u) ? rbase + coloff[q] : 0x80000000u;
-            row[q].q[0] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
-            if constexpr (DT == PCV_F32) row[q].q[1] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 16, 0);
+            raw_load<DT, CPT>(xrsrc, off, row[q]);
         }
     };
 
-    f32x2 win[KS][KS][4];                // slot-indexed rows; row r of the current window lives in slot (r + S*phase) % KS
+    f32x2 win[KS][KS][NV];               // slot-indexed rows; row r of the current window lives in slot (r + S*phase) % KS
     constexpr int PD = (KS == 3 && S == 1) ? 3 : 1;   // prefetch depth in output rows; divides the unroll period (static ring slots)
-    RawChunk<DT> raw[PD][NEW][KS];       // ring: raw[t % PD] holds the NEW rows of output row t (relative to ho_begin)
+    RawChunk<DT, CPT> raw[PD][NEW][KS];       // ring: raw[t % PD] holds the NEW rows of output row t (relative to ho_begin)
 
     // prologue: the KEEP rows shared with the first output row go straight into the window; the NEW rows of the first
     // PD output rows are requested up front
     const int hi_first = ho_begin * S - p.pt;
     {
-        RawChunk<DT> tmp[KEEP > 0 ? KEEP : 1][KS];
+        RawChunk<DT, CPT> tmp[KEEP > 0 ? KEEP : 1][KS];
 #pragma unroll
         for (int r = 0; r < KEEP; ++r) fetch_row(hi_first + r, tmp[r]);
 #pragma unroll
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 #pragma unroll
         for (int r = 0; r < KEEP; ++r)
 #pragma unroll
-            for (int q = 0; q < KS; ++q) raw_to_f32x2<DT>(tmp[r][q], win[r][q]);
+            for (int q = 0; q < KS; ++q) raw_to_f32x2<DT, CPT>(tmp[r][q], win[r][q]);
     }
 
     int ho = ho_begin;
@@ -202,46 +234,46 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 #pragma unroll
                 for (int r = 0; r < NEW; ++r)
 #pragma unroll
-                    for (int q = 0; q < KS; ++q) raw_to_f32x2<DT>(raw[PH % PD][r][q], win[(KEEP + r + S * PH) % KS][q]);
+                    for (int q = 0; q < KS; ++q) raw_to_f32x2<DT, CPT>(raw[PH % PD][r][q], win[(KEEP + r + S * PH) % KS][q]);
                 // refill the slot with the rows of output row ho + PD before doing this row's arithmetic
                 {
                     const bool need = ho + PD < ho_end;
 #pragma unroll
                     for (int r = 0; r < NEW; ++r) fetch_row(need ? hi + PD * S + KEEP + r : -1, raw[PH % PD][r]);
                 }
-                f32x2 acc[4];
+                f32x2 acc[NV];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = pk_mul(win[(S * PH) % KS][0][e], wgt[0][e]);
+                for (int e = 0; e < NV; ++e) acc[e] = pk_mul(win[(S * PH) % KS][0][e], wgt[0][e]);
 #pragma unroll
                 for (int r = 0; r < KS; ++r)
 #pragma unroll
                     for (int q = 0; q < KS; ++q) {
                         if (r == 0 && q == 0) continue;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < NV; ++e)
                             pk_fma_acc(acc[e], win[(r + S * PH) % KS][q][e], wgt[r * KS + q][e]);
                     }
 
                 const size_t eoff = (((size_t)n * p.Ho + ho) * p.Wo + wo) * p.C + c0;
-                float v[8];
+                float v[CPT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < NV; ++e) {
                     f32x2 t2 = sf[e];
                     pk_fma_acc(t2, acc[e], sc[e]);
                     v[2 * e] = t2[0];
                     v[2 * e + 1] = t2[1];
                 }
-                if constexpr (FAST) clamp8(v, act); else apply_act8(v, act);
+                if constexpr (FAST) clampn(v, act); else apply_actn(v, act);
                 if (p.res != nullptr) {
-                    float r8[8];
-                    load8<DT>(p.res, eoff, r8);
+                    float r8[CPT];
+                    loadn<DT, CPT>(p.res, eoff, r8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r8[e];
+                    for (int e = 0; e < CPT; ++e) v[e] += r8[e];
                 }
                 if (p.post_act != PCV_ACT_NONE) {
-                    if constexpr (FAST) clamp8(v, pact); else apply_act8(v, pact);
+                    if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
                 }
-                store8<DT>(p.y, eoff, v);
+                storen<DT, CPT>(p.y, eoff, v);
                 ++ho;
                 hi += S;
             }

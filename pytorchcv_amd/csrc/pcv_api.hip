@@ -339,8 +339,8 @@ static int enable_stem(pcv_ctx* ctx) {
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
     else if (d.kh == 3) dwconv_kernel<DT, 3, 2, FAST><<<grid, 256, 0, s>>>(p);
-    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1, FAST><<<grid, 256, 0, s>>>(p);
-    else dwconv_kernel<DT, 5, 2, FAST><<<grid, 256, 0, s>>>(p);
+    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1, FAST, 4><<<grid, 256, 0, s>>>(p);     // 5x5: 4 channels per thread
+    else dwconv_kernel<DT, 5, 2, FAST, 4><<<grid, 256, 0, s>>>(p);
 }
 template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.act <= PCV_ACT_RELU6 && d.post_act <= PCV_ACT_RELU6) launch_dw2<DT, true>(d, p, grid, s);
@@ -764,7 +764,7 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.Wo = (d->W + d->pad_l + d->pad_r - (d->kw - 1) - 1) / d->stride_w + 1;
     if (p.Ho <= 0 || p.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_dwconv2d_fused: empty output");
     p.pt = d->pad_t; p.pl = d->pad_l;
-    p.C8 = d->Cin / 8;
+    p.C8 = d->Cin / (d->kh == 5 ? 4 : 8);          // channel chunks per pixel (5x5 runs 4 channels per thread)
     // rows per thread: whole column when that still fills the chip (>= ~16 waves per CU), else shorter strips
     const long cols = (long)d->N * p.Wo * p.C8;
     const long want = (long)ctx->num_cu * 64 * 16;

@@ -91,6 +91,18 @@ __device__ __forceinline__ ActClamp make_act(int act) {
     a.hi = act == PCV_ACT_RELU6 ? 6.f : INFINITY;
     return a;
 }
+template <int N> __device__ __forceinline__ void clampn(float (&v)[N], const ActClamp& a) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);
+}
+template <int N> __device__ __forceinline__ void apply_actn(float (&v)[N], const ActClamp& a) {
+    if (a.slow) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = apply_act(v[e], a.code);
+    } else {
+        clampn<N>(v, a);
+    }
+}
 __device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);

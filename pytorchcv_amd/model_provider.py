@@ -13,9 +13,10 @@ from .models import resnext as _resnext
 from .models import seresnet as _seresnet
 from .models import seresnext as _seresnext
 from .models import mobilenet as _mobilenet
+from .models import mobilenetv3 as _mobilenetv3
 
 _models = {}
-for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet):
+for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet, _mobilenetv3):
     for _name in _mod.__all__:
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith("get_") and callable(_fn):

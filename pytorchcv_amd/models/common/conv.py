@@ -17,10 +17,11 @@ from ... import engine
 class BareConv(nn.Conv2d):
     """nn.Conv2d parameter holder whose forward is the fused MI355X kernel without BN/activation (reference bare
     `conv1x1`, conv.py:89-119: SE convolutions, MobileNetV2 classifier)."""
-    def forward(self, x, out_fp32: bool = False):
+    def forward(self, x, out_fp32: bool = False, act: int = 0):
+        """`act`: engine.act_code of the activation module that follows this convolution in the reference (fused)."""
         if getattr(self, "_pcv_runner", None) is None:
             self._pcv_runner = engine.ConvRunner(self, None)
-        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, out_fp32=out_fp32))
+        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, out_fp32=out_fp32))
 
 
 def conv1x1(in_channels, out_channels, stride=1, groups=1, bias=False):

@@ -97,7 +97,7 @@ def images(ids):
 def make_model(ref_models, name):
     mod = {"resnet18": "resnet", "resnet50": "resnet", "mobilenetv2_w1": "mobilenetv2",
            "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
-           "mobilenet_w1": "mobilenet"}[name]
+           "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 
@@ -145,13 +145,14 @@ def build_block(case):
     from pytorchcv.models.mobilenetv2 import LinearBottleneck
     from pytorchcv.models.resnext import ResNeXtUnit
     from pytorchcv.models.seresnet import SEResUnit
+    from pytorchcv.models.mobilenetv3 import MobileNetV3Unit
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
     ctor = {"ConvBlock": C.ConvBlock, "conv1x1_block": C.conv1x1_block, "conv3x3_block": C.conv3x3_block,
             "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
             "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
-            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit}[kind]
+            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit}[kind]
     return ctor(**kw).eval()
 
 
