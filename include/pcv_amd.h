@@ -117,6 +117,9 @@ int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int
  * global-average-pool of the classifier tail. fp32 accumulation. */
 int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s,
                   int dtype, int out_dtype, void* stream);
+/* nn.AdaptiveAvgPool2d(output_size=1) `final_pool` (efficientnet.py:339): mean over the HW positions of any map shape. */
+int pcv_global_avgpool(pcv_ctx* ctx, const void* x, void* y, int N, int HW, int C, int dtype, int out_dtype,
+                       void* stream);
 /* nn.Linear (resnet.py:320-322,336) / bias-free 1x1 classifier conv (mobilenetv2.py:138-141,154):
  * y[N,Cout] (out_dtype) = x[N,Cin] (dtype) . W^T + bias. `packed` comes from pcv_conv_pack with kh=kw=1. */
 int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* bias, void* y,

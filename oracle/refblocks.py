@@ -5,14 +5,15 @@
     tests/golden/cases.py) over a state_dict, in reference-exact fp32 mode or quantisation-matched 16-bit mode
     (see oracle/refnet.py). Reference lines: common/conv.py:204-543 (ConvBlock and factories), common/att.py:94-105
     (SEBlock), resnet.py:143-263 (ResUnit, ResInitBlock), mobilenetv2.py:16-71 (LinearBottleneck), resnext.py:17-116
-    (ResNeXtUnit), seresnet.py:17-72 (SEResUnit), mobilenetv3.py:18-93 (MobileNetV3Unit).
+    (ResNeXtUnit), seresnet.py:17-72 (SEResUnit), mobilenetv3.py:18-93 (MobileNetV3Unit),
+    efficientnet.py:58-239 (EffiDwsConvUnit, EffiInvResUnit, EffiInitBlock).
 """
 
 __all__ = ['block_forward']
 
 import torch
 import torch.nn.functional as F
-from .refnet import Quant, conv_block, se_block, _res_body
+from .refnet import Quant, conv_block, se_block, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit
 
 _KSIZE = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv5x5_block": (5, 2), "conv7x7_block": (7, 3),
           "dwconv3x3_block": (3, 1), "dwconv5x5_block": (5, 2)}
@@ -67,6 +68,14 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
             if kw["use_se"]:
                 y = se_block(sd, "se.", y, q=q, out_act="hsigmoid")
             return conv_block(sd, "conv2.", y, act=None, q=q, residual=residual)
+        if kind == "EffiInitBlock":
+            # efficientnet.py:235-239
+            pad = tf_same_pad(x.shape[2], x.shape[3], 3, 2) if kw["tf_mode"] else 1
+            return conv_block(sd, "conv.", x, stride=2, padding=pad, act="swish", q=q, eps=kw["bn_eps"])
+        if kind == "EffiDwsConvUnit":
+            return effi_dws_unit(sd, "", x, q, kw["tf_mode"], kw["bn_eps"], residual_ok=(kw["stride"] == 1))
+        if kind == "EffiInvResUnit":
+            return effi_inv_res_unit(sd, "", x, q, kw["stride"], kw["tf_mode"], kw["bn_eps"])
         if kind == "ResInitBlock":
             y = conv_block(sd, "conv.", x, stride=2, padding=3, q=q)
             return F.max_pool2d(y, kernel_size=3, stride=2, padding=1)

@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -372,6 +372,69 @@ def mobilenetv3_forward(sd, x, version="large", q=None, taps=None):
     return x.view(x.size(0), -1)
 
 
+def tf_same_pad(h, w, kernel_size, stride=1, dilation=1):
+    """calc_tf_padding, efficientnet.py:27-55. Returned in F.pad order: the reference hands (pad_h//2, pad_h - pad_h//2,
+    pad_w//2, pad_w - pad_w//2) to F.pad, which reads it as (left, right, top, bottom)."""
+    oh = math.ceil(float(h) / stride)
+    ow = math.ceil(float(w) / stride)
+    pad_h = max((oh - 1) * stride + (kernel_size - 1) * dilation + 1 - h, 0)
+    pad_w = max((ow - 1) * stride + (kernel_size - 1) * dilation + 1 - w, 0)
+    return (pad_h // 2, pad_h - pad_h // 2, pad_w // 2, pad_w - pad_w // 2)
+
+
+def effi_dws_unit(sd, p, x, q, tf_mode, eps, residual_ok=True):
+    """EffiDwsConvUnit.forward, efficientnet.py:105-115 (the depthwise conv always has stride 1)."""
+    out_ch = sd[p + "pw_conv.conv.weight"].shape[0]
+    residual = x if (residual_ok and x.shape[1] == out_ch) else None
+    pad = tf_same_pad(x.shape[2], x.shape[3], 3) if tf_mode else 1
+    y = conv_block(sd, p + "dw_conv.", x, padding=pad, groups=x.shape[1], act="swish", q=q, eps=eps)
+    y = se_block(sd, p + "se.", y, q=q, mid_act="swish")
+    return conv_block(sd, p + "pw_conv.", y, act=None, q=q, residual=residual, eps=eps)
+
+
+def effi_inv_res_unit(sd, p, x, q, stride, tf_mode, eps):
+    """EffiInvResUnit.forward, efficientnet.py:185-197."""
+    out_ch = sd[p + "conv3.conv.weight"].shape[0]
+    residual = x if (x.shape[1] == out_ch and stride == 1) else None
+    y = conv_block(sd, p + "conv1.", x, act="swish", q=q, eps=eps)
+    wdw = sd[p + "conv2.conv.weight"]
+    k = wdw.shape[-1]
+    pad = tf_same_pad(y.shape[2], y.shape[3], k, stride) if tf_mode else k // 2
+    y = conv_block(sd, p + "conv2.", y, stride=stride, padding=pad, groups=wdw.shape[0], act="swish", q=q, eps=eps)
+    if (p + "se.conv1.weight") in sd:
+        y = se_block(sd, p + "se.", y, q=q, mid_act="swish")
+    return conv_block(sd, p + "conv3.", y, act=None, q=q, residual=residual, eps=eps)
+
+
+def efficientnet_forward(sd, x, version="b0", tf_mode=False, bn_eps=1e-5, q=None, taps=None):
+    """EfficientNet.forward (efficientnet.py:354-358); stage/stride plan of get_efficientnet (:441-466) - the number of
+    units per stage is read from the state_dict, the per-stage strides are those of the reference table."""
+    q = q or Quant(None)
+    strides = [1, 2, 2, 2, 2]              # strides_per_stage after merging the non-downsampling layers (:448,463-465)
+    x = q.r(x)
+    pad = tf_same_pad(x.shape[2], x.shape[3], 3, 2) if tf_mode else 1
+    x = conv_block(sd, "features.init_block.conv.", x, stride=2, padding=pad, act="swish", q=q, eps=bn_eps)
+    _tap(taps, "init_block", x)
+    for i, stage_stride in enumerate(strides):
+        j = 0
+        while True:
+            p = "features.stage{}.unit{}.".format(i + 1, j + 1)
+            if i == 0:
+                if (p + "dw_conv.conv.weight") not in sd:
+                    break
+                x = effi_dws_unit(sd, p, x, q, tf_mode, bn_eps, residual_ok=(stage_stride == 1 or j > 0))
+            else:
+                if (p + "conv1.conv.weight") not in sd:
+                    break
+                x = effi_inv_res_unit(sd, p, x, q, stage_stride if j == 0 else 1, tf_mode, bn_eps)
+            j += 1
+        _tap(taps, "stage{}".format(i + 1), x)
+    x = conv_block(sd, "features.final_block.", x, act="swish", q=q, eps=bn_eps)
+    x = q.r(x.mean(dim=(2, 3), keepdim=True))                              # AdaptiveAvgPool2d(1), :339
+    x = x.view(x.size(0), -1)
+    return F.linear(x, q.r(sd["output.fc.weight"].float()), sd["output.fc.bias"].float())   # dropout: identity in eval
+
+
 MODEL_ARCH = {
     "resnet18": ("resnet", dict(blocks=18)),
     "resnet34": ("resnet", dict(blocks=34)),
@@ -397,11 +460,15 @@ MODEL_ARCH = {
 for _v in ("small", "large"):
     for _t in ("w7d20", "wd2", "w3d4", "w1", "w5d4"):
         MODEL_ARCH["mobilenetv3_{}_{}".format(_v, _t)] = ("mobilenetv3", dict(version=_v))
+for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
+    MODEL_ARCH["efficientnet_" + _v] = ("efficientnet", dict(version=_v))
+    for _t in ("b", "c"):
+        MODEL_ARCH["efficientnet_" + _v + _t] = ("efficientnet", dict(version=_v, tf_mode=True, bn_eps=1e-3))
 
 
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
            "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
-           "mobilenetv3": mobilenetv3_forward}
+           "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

@@ -48,6 +48,7 @@ _SIGS = {
     "pcv_dwconv2d_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pcv_maxpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_avgpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "pcv_global_avgpool": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_gemm_bias": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_se_squeeze": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "pcv_se_excite": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),

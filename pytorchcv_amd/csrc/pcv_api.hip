@@ -827,6 +827,20 @@ int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int
     return PCV_OK;
 }
 
+int pcv_global_avgpool(pcv_ctx* ctx, const void* x, void* y, int N, int HW, int C, int dtype, int out_dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !y || N <= 0 || HW <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype) ||
+        (out_dtype != dtype && out_dtype != PCV_F32))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_global_avgpool: bad argument (C must be a multiple of 8)");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) launch_mean<PCV_BF16>(x, y, N, HW, C, out_dtype, st);
+    else if (dtype == PCV_F16) launch_mean<PCV_F16>(x, y, N, HW, C, out_dtype, st);
+    else launch_mean<PCV_F32>(x, y, N, HW, C, out_dtype, st);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
 int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* bias, void* y, int N, int Cin,
                   int Cout, int dtype, int out_dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;

@@ -165,7 +165,8 @@ class ConvRunner(object):
         return ts
 
     def _state_key(self, dtype, cpitch):
-        return (dtype, cpitch) + tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
+        # pad4 is part of the key: the stem packing depends on the parity of the left padding (TF-"same" mode changes it)
+        return (dtype, cpitch, self.pad4) + tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
 
     def desc(self, x: NHWC, act, post_act, has_res, out_code=None) -> ConvDesc:
         c = self.conv
@@ -224,7 +225,11 @@ class ConvRunner(object):
         torch.cuda.current_stream(dev).synchronize()      # w32 & friends are temporaries; load-time only
         self.packed, self.scale, self.shift, self._key = packed, scale, shift, key
 
-    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False) -> NHWC:
+    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None) -> NHWC:
+        """`pad4`: explicit (left, right, top, bottom) zero padding for this call (the `F.pad` a unit applies in front of
+        a padding-0 convolution, efficientnet.py:108-109,189-190,236-237); it stays inside the kernel's bounds checks."""
+        if pad4 is not None:
+            self.pad4 = tuple(int(v) for v in pad4)
         if self.bn is not None and self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
         d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None)
@@ -283,6 +288,17 @@ def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
     code = _CODE_OF_TORCH[x.dtype]
     _lib.check(_lib.lib().pcv_avgpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, code, code, _stream(x.device)), ctx)
     return NHWC(y, x.N, Ho, Wo, x.C)
+
+
+def global_avgpool(x: NHWC) -> NHWC:
+    """nn.AdaptiveAvgPool2d(1) -> [N,1,1,C]."""
+    if not x.dense:
+        raise RuntimeError("avg-pool on a padded handle")
+    y = torch.empty((x.N, 1, 1, x.C), dtype=x.dtype, device=x.device)
+    ctx = _ctx(x.device)
+    code = _CODE_OF_TORCH[x.dtype]
+    _lib.check(_lib.lib().pcv_global_avgpool(ctx, _ptr(x.t), _ptr(y), x.N, x.H * x.W, x.C, code, code, _stream(x.device)), ctx)
+    return NHWC(y, x.N, 1, 1, x.C)
 
 
 def se_forward(x: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int, residual: NHWC | None, post_act: int) -> NHWC:

@@ -3,7 +3,7 @@
     nn.AvgPool2d (same attribute names, no state), the classifier tail and the pretrained-weights hook of every factory.
 """
 
-__all__ = ['MaxPool2dNHWC', 'AvgPool2dNHWC', 'LinearHead', 'run_net', 'maybe_load_pretrained', 'init_conv_params']
+__all__ = ['MaxPool2dNHWC', 'AvgPool2dNHWC', 'GlobalAvgPool2dNHWC', 'LinearHead', 'run_net', 'maybe_load_pretrained', 'init_conv_params']
 
 import os
 import torch
@@ -29,6 +29,18 @@ class AvgPool2dNHWC(nn.Module):
 
     def forward(self, x):
         return engine.boundary(self, x, lambda a: engine.avgpool2d(a, self.kernel_size, self.stride))
+
+
+class GlobalAvgPool2dNHWC(nn.Module):
+    """nn.AdaptiveAvgPool2d(output_size=1) `final_pool` (reference efficientnet.py:339) -> pcv_global_avgpool."""
+    def __init__(self, output_size=1):
+        super(GlobalAvgPool2dNHWC, self).__init__()
+        if output_size != 1:
+            raise NotImplementedError("only AdaptiveAvgPool2d(1) is on the MI355X path")
+        self.output_size = output_size
+
+    def forward(self, x):
+        return engine.boundary(self, x, engine.global_avgpool)
 
 
 class LinearHead(nn.Linear):

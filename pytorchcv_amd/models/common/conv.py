@@ -68,12 +68,13 @@ class ConvBlock(nn.Module):
                 assert isinstance(self.activ, nn.Module)
         self._pcv_runner = None
 
-    def forward(self, x, residual=None, post_act=None):
+    def forward(self, x, residual=None, post_act=None, pad4=None):
         if self._pcv_runner is None:
             self._pcv_runner = engine.ConvRunner(self.conv, self.bn if self.normalize else None, pad4=self._pad4)
         act = engine.act_code(self.activ) if self.activate else 0
         pact = engine.act_code(post_act)
-        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact))
+        return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact,
+                                                                       pad4=pad4))
 
 
 def conv1x1_block(padding=0, **kwargs):

@@ -97,7 +97,8 @@ def images(ids):
 def make_model(ref_models, name):
     mod = {"resnet18": "resnet", "resnet50": "resnet", "mobilenetv2_w1": "mobilenetv2",
            "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
-           "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3"}[name]
+           "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3",
+           "efficientnet_b0": "efficientnet", "efficientnet_b0b": "efficientnet"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 
@@ -146,13 +147,20 @@ def build_block(case):
     from pytorchcv.models.resnext import ResNeXtUnit
     from pytorchcv.models.seresnet import SEResUnit
     from pytorchcv.models.mobilenetv3 import MobileNetV3Unit
+    from pytorchcv.models.efficientnet import EffiInitBlock, EffiDwsConvUnit, EffiInvResUnit
+    from pytorchcv.models.common.activ import lambda_swish
+    from pytorchcv.models.common.norm import lambda_batchnorm2d
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
+    if kind.startswith("Effi"):
+        kw["normalization"] = lambda_batchnorm2d(eps=kw.pop("bn_eps"))
+        kw["activation"] = lambda_swish()
     ctor = {"ConvBlock": C.ConvBlock, "conv1x1_block": C.conv1x1_block, "conv3x3_block": C.conv3x3_block,
             "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
             "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
-            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit}[kind]
+            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit,
+            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit}[kind]
     return ctor(**kw).eval()
 
 

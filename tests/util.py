@@ -52,13 +52,20 @@ def build_block(case):
     from pytorchcv_amd.models.resnext import ResNeXtUnit
     from pytorchcv_amd.models.seresnet import SEResUnit
     from pytorchcv_amd.models.mobilenetv3 import MobileNetV3Unit
+    from pytorchcv_amd.models.efficientnet import EffiInitBlock, EffiDwsConvUnit, EffiInvResUnit
+    from pytorchcv_amd.models.common.activ import lambda_swish
+    from pytorchcv_amd.models.common.norm import lambda_batchnorm2d
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
+    if kind.startswith("Effi"):
+        kw["normalization"] = lambda_batchnorm2d(eps=kw.pop("bn_eps"))
+        kw["activation"] = lambda_swish()
     ctor = {"ConvBlock": C.ConvBlock, "conv1x1_block": C.conv1x1_block, "conv3x3_block": C.conv3x3_block,
             "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
             "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
-            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit}[kind]
+            "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit,
+            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit}[kind]
     return ctor(**kw).eval()
 
 
