@@ -30,6 +30,8 @@ WORKLOADS = {
     "mobilenetv2_w1_bs512": ("mobilenetv2_w1", 512, "depthwise", "hbm"),
     "resnext101_32x4d_bs256": ("resnext101_32x4d", 256, "grouped3x3", "hbm"),
     "resnet18_bs256": ("resnet18", 256, "dense3x3", "mfma"),
+    "mobilenetv3_large_w1_bs512": ("mobilenetv3_large_w1", 512, "depthwise", "hbm"),
+    "efficientnet_b0_bs256": ("efficientnet_b0", 256, "depthwise", "hbm"),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"

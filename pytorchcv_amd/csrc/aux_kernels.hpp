@@ -193,66 +193,142 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const void* __restrict__ x
     store8<OT>(y, (size_t)i * 8, a);
 }
 
-// Spatial mean over HW positions: global average pool (AvgPool2d(7) on a 7x7 map, resnet.py:316-318) and the SE
-// squeeze (AdaptiveAvgPool2d(1), att.py:72). Block = (image n, slab of 256 channels); 32 lanes x 8 channels across,
-// 8 thread-rows striding over HW, fp32 partials reduced through LDS.
+// Spatial mean over HW positions: global average pool (AvgPool2d(7) on a 7x7 map, resnet.py:316-318; AdaptiveAvgPool2d(1),
+// efficientnet.py:339) and the SE squeeze (att.py:95). One 512-thread block per (image, group of <= 512 channel chunks):
+// the threads tile [rows x chunks] so that a block reads one contiguous span of the NHWC map per iteration whatever the
+// channel count (C = 32 keeps all 512 threads busy, 128 rows at a time), fp32 accumulation, rows meet in LDS.
 template <int DT, int OT>
-__global__ __launch_bounds__(256) void spatial_mean_kernel(const void* __restrict__ x, void* __restrict__ y, int HW, int C) {
-    __shared__ float part[8][32][8];
+__global__ __launch_bounds__(512) void spatial_mean_kernel(const void* __restrict__ x, void* __restrict__ y, int HW, int C) {
+    __shared__ float part[512][9];                       // +1: the row-sum reads below walk it with a stride of Gc rows
     const int n = blockIdx.x;
-    const int lane32 = threadIdx.x & 31, row = threadIdx.x >> 5;
-    const int c0 = (blockIdx.y * 32 + lane32) * 8;
+    const int C8 = C >> 3;
+    const int g0 = blockIdx.y * 512;
+    const int Gc = min(512, C8 - g0);                    // chunks of this group
+    const int R = 512 / Gc;                              // rows in flight
+    const int t = threadIdx.x;
+    const int r = t / Gc, c = t - r * Gc;
     float a[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    if (c0 < C) {
-        for (int hw = row; hw < HW; hw += 8) {
+    if (r < R) {
+        const size_t base = (size_t)n * HW * C + (size_t)(g0 + c) * 8;
+#pragma unroll 4
+        for (int hw = r; hw < HW; hw += R) {
             float v[8];
-            load8<DT>(x, ((size_t)n * HW + hw) * C + c0, v);
+            load8<DT>(x, base + (size_t)hw * C, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] += v[e];
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[row][lane32][e] = a[e];
+    for (int e = 0; e < 8; ++e) part[t][e] = a[e];
     __syncthreads();
-    if (row == 0 && c0 < C) {
+    if (t < Gc) {
         const float inv = 1.f / (float)HW;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float s = 0.f;
+        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int q = 0; q < R; ++q)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) s += part[r][lane32][e];
-            a[e] = s * inv;
-        }
-        store8<OT>(y, (size_t)n * C + c0, a);
+            for (int e = 0; e < 8; ++e) a[e] += part[q * Gc + t][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= inv;
+        store8<OT>(y, (size_t)n * C + (size_t)(g0 + t) * 8, a);
     }
 }
 
-// ---- SE excitation (att.py:96-103): gate = out_act(W2 . mid_act(W1 . mean + b1) + b2), one block per image -------
+// ---- SE excitation (att.py:96-103): gate = out_act(W2 . mid_act(W1 . mean + b1) + b2) -----------------------------------
+// One block computes IMG images so that every weight element fetched is used IMG times (the two layers are small GEMMs
+// over the batch: one block per image re-read both matrices from L2 for every image and was the slowest kernel of
+// MobileNetV3). fp32 throughout. Thread mapping, layer 1: row m = t % TM, the C range is split over the 256 / TM
+// thread groups and the partial sums meet in LDS; layer 2: one thread per output channel. The means / mid activations
+// are LDS broadcasts.
+template <int IMG>
 __global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ gate, int C,
-                                                       int M, int mid_act, int out_act) {
-    extern __shared__ float sm[];       // [C] mean, then [M] mid
-    float* smean = sm;
-    float* smid = sm + C;
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) smean[c] = mean[(size_t)n * C + c];
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int N, int C,
+                                                       int M, int TM, int mid_act, int out_act) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* smean = sm;                       // [IMG][C]
+    float* smid = sm + IMG * C;              // [IMG][Mp]  (Mp = M rounded up to 4)
+    const int Mp = (M + 3) & ~3;
+    float* spart = smid + IMG * Mp;          // [P][IMG][TM]
+    const int n0 = blockIdx.x * IMG;
+    const int t = threadIdx.x;
+    for (int i = t; i < IMG * C; i += 256) {
+        const int img = i / C;
+        smean[i] = n0 + img < N ? mean[(size_t)n0 * C + i] : 0.f;
+    }
+    for (int i = t; i < IMG * Mp; i += 256) smid[i] = 0.f;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int m = wave; m < M; m += 4) {
-        float a = 0.f;
-        for (int c = lane; c < C; c += 64) a += w1[(size_t)m * C + c] * smean[c];
+
+    // ---- layer 1 ------------------------------------------------------------------------------------------------------
+    const int P = 256 / TM;
+    const int tx = t % TM, ty = t / TM;
+    const int Cp = ((C / 4 + P - 1) / P) * 4;                    // channels per partition (C % 8 == 0)
+    const int cbeg = min(C, ty * Cp), cend = min(C, cbeg + Cp);
+    for (int mb = 0; mb < M; mb += TM) {
+        const int m = mb + tx;
+        float acc[IMG];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-        if (lane == 0) smid[m] = apply_act(a + b1[m], mid_act);
+        for (int i = 0; i < IMG; ++i) acc[i] = 0.f;
+        if (m < M) {
+            const float* wr = w1 + (size_t)m * C;
+            for (int c = cbeg; c < cend; c += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
+#pragma unroll
+                for (int i = 0; i < IMG; ++i) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smean + i * C + c);
+                    acc[i] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+                }
+            }
+        }
+        if (P > 1) {
+#pragma unroll
+            for (int i = 0; i < IMG; ++i) spart[(ty * IMG + i) * TM + tx] = acc[i];
+            __syncthreads();
+            for (int j = t; j < IMG * TM; j += 256) {
+                const int i = j / TM, r = j % TM;
+                if (mb + r < M) {
+                    float a = b1[mb + r];
+                    for (int q = 0; q < P; ++q) a += spart[(q * IMG + i) * TM + r];
+                    smid[i * Mp + mb + r] = apply_act(a, mid_act);
+                }
+            }
+            __syncthreads();
+        } else if (m < M) {
+            const float bias = b1[m];
+#pragma unroll
+            for (int i = 0; i < IMG; ++i) smid[i * Mp + m] = apply_act(acc[i] + bias, mid_act);
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = b2[c];
-        for (int m = 0; m < M; ++m) a += w2[(size_t)c * M + m] * smid[m];
-        gate[(size_t)n * C + c] = apply_act(a, out_act);
+
+    // ---- layer 2 ------------------------------------------------------------------------------------------------------
+    for (int c = t; c < C; c += 256) {
+        float acc[IMG];
+        const float bias = b2[c];
+#pragma unroll
+        for (int i = 0; i < IMG; ++i) acc[i] = bias;
+        const float* wr = w2 + (size_t)c * M;
+        if ((M & 3) == 0) {
+            for (int m = 0; m < M; m += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + m);
+#pragma unroll
+                for (int i = 0; i < IMG; ++i) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(smid + i * Mp + m);
+                    acc[i] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+                }
+            }
+        } else {
+            for (int m = 0; m < M; ++m) {
+                const float w = wr[m];
+#pragma unroll
+                for (int i = 0; i < IMG; ++i) acc[i] += w * smid[i * Mp + m];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IMG; ++i)
+            if (n0 + i < N) gate[(size_t)(n0 + i) * C + c] = apply_act(acc[i], out_act);
     }
 }
 

@@ -347,9 +347,9 @@ template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& 
     else launch_dw2<DT, false>(d, p, grid, s);
 }
 template <int DT> static void launch_mean(const void* x, void* y, int N, int HW, int C, int ot, hipStream_t s) {
-    dim3 grid((unsigned)N, (unsigned)((C + 255) / 256));
-    if (ot == PCV_F32) spatial_mean_kernel<DT, PCV_F32><<<grid, 256, 0, s>>>(x, y, HW, C);
-    else spatial_mean_kernel<DT, DT><<<grid, 256, 0, s>>>(x, y, HW, C);
+    dim3 grid((unsigned)N, (unsigned)((C / 8 + 511) / 512));
+    if (ot == PCV_F32) spatial_mean_kernel<DT, PCV_F32><<<grid, 512, 0, s>>>(x, y, HW, C);
+    else spatial_mean_kernel<DT, DT><<<grid, 512, 0, s>>>(x, y, HW, C);
 }
 template <int DT> static void launch_avg(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int k, int s,
                                          int ot, hipStream_t st) {
@@ -873,9 +873,20 @@ int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float*
     DeviceGuard device_guard(ctx->device);
     if (!mean || !w1 || !b1 || !w2 || !b2 || !gate || N <= 0 || C <= 0 || M <= 0)
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: bad argument");
-    const size_t lds = (size_t)(C + M) * sizeof(float);
+    if (C % 8 != 0 || C > 8192 || M > 8192)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: C must be a multiple of 8, C and M at most 8192");
+    int TM = 8;
+    while (TM < M && TM < 256) TM *= 2;
+    const int img = C <= 1024 ? 8 : C <= 2048 ? 4 : C <= 4096 ? 2 : 1;       // [img][C] fp32 means stay within 32 KB of LDS
+    const int Mp = (M + 3) & ~3;
+    const size_t lds = ((size_t)img * C + (size_t)img * Mp + (size_t)256 * img) * sizeof(float);
     if (lds > 64 * 1024) return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: C + M too large");
-    se_excite_kernel<<<N, 256, lds, (hipStream_t)stream>>>(mean, w1, b1, w2, b2, gate, C, M, mid_act, out_act);
+    const int grid = (N + img - 1) / img;
+    hipStream_t st = (hipStream_t)stream;
+    if (img == 8) se_excite_kernel<8><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
+    else if (img == 4) se_excite_kernel<4><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
+    else if (img == 2) se_excite_kernel<2><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
+    else se_excite_kernel<1><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

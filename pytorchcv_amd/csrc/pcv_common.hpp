@@ -69,8 +69,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case PCV_ACT_RELU: return fmaxf(v, 0.f);                                   // activ.py:64
         case PCV_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);                      // activ.py:81
-        case PCV_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));                     // activ.py:132
-        case PCV_ACT_SWISH: return v / (1.f + __expf(-v));                         // activ.py:20-21
+        case PCV_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));        // activ.py:132 (v_rcp_f32: 1 ulp)
+        case PCV_ACT_SWISH: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));      // activ.py:20-21
         case PCV_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);      // activ.py:29-30
         case PCV_ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);    // activ.py:46-47
         default: return v;
