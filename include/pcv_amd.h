@@ -126,9 +126,11 @@ int pcv_gemm_bias(pcv_ctx* ctx, const void* x, const void* packed, const float* 
                   int N, int Cin, int Cout, int dtype, int out_dtype, void* stream);
 /* SEBlock (common/att.py:94-105): squeeze = AdaptiveAvgPool2d(1) -> mean fp32 [N,C]. */
 int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int C, int dtype, void* stream);
-/* gate[N,C] = out_act(W2 . mid_act(W1 . mean + b1) + b2); W1 fp32 [M,C], W2 fp32 [C,M] (att.py:76-92). */
+/* mid[N,M] = mid_act(W1 . mean + b1); gate[N,C] = out_act(W2 . mid + b2); W1 fp32 [M,C], W2 fp32 [C,M]
+ * (att.py:76-92). `mid` is caller-provided fp32 storage for the hidden activations (two launches). */
 int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2,
-                  const float* b2, float* gate, int N, int C, int M, int mid_act, int out_act, void* stream);
+                  const float* b2, float* mid, float* gate, int N, int C, int M, int mid_act, int out_act,
+                  void* stream);
 /* y = post_act(x * gate[n,c] + residual) (att.py:104 + seresnet.py:69-71); residual may be NULL. */
 int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y,
                  int N, int HW, int C, int post_act, int dtype, void* stream);

@@ -237,98 +237,69 @@ __global__ __launch_bounds__(512) void spatial_mean_kernel(const void* __restric
 }
 
 // ---- SE excitation (att.py:96-103): gate = out_act(W2 . mid_act(W1 . mean + b1) + b2) -----------------------------------
-// One block computes IMG images so that every weight element fetched is used IMG times (the two layers are small GEMMs
-// over the batch: one block per image re-read both matrices from L2 for every image and was the slowest kernel of
-// MobileNetV3). fp32 throughout. Thread mapping, layer 1: row m = t % TM, the C range is split over the 256 / TM
-// thread groups and the partial sums meet in LDS; layer 2: one thread per output channel. The means / mid activations
-// are LDS broadcasts.
-template <int IMG>
-__global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                       const float* __restrict__ b2, float* __restrict__ gate, int N, int C,
-                                                       int M, int TM, int mid_act, int out_act) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* smean = sm;                       // [IMG][C]
-    float* smid = sm + IMG * C;              // [IMG][Mp]  (Mp = M rounded up to 4)
-    const int Mp = (M + 3) & ~3;
-    float* spart = smid + IMG * Mp;          // [P][IMG][TM]
+// Both layers are the same small fp32 GEMM over the batch, out[n][j] = act(b[j] + sum_k W[j][k] * in[n][k]), launched
+// twice. A block owns 8 images x TJ output rows, so every weight element fetched is used 8 times and the grid has
+// (N / 8) x (J / TJ) blocks (one block per image re-read both matrices for every image and was the slowest kernel of
+// MobileNetV3). Thread (jx, kp): output row jx of the block, K partition kp of 256 / TJ; inputs are LDS broadcasts
+// staged 1024 columns at a time; the partitions meet in LDS.
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int N, int K,
+                                                   int J, int TJ, int act) {
+    constexpr int IMG = 8, KC = 1024;
+    __shared__ __attribute__((aligned(16))) float sin[IMG][KC];
+    __shared__ float spart[256 * IMG];                           // [P][IMG][TJ]
     const int n0 = blockIdx.x * IMG;
+    const int j0 = blockIdx.y * TJ;
     const int t = threadIdx.x;
-    for (int i = t; i < IMG * C; i += 256) {
-        const int img = i / C;
-        smean[i] = n0 + img < N ? mean[(size_t)n0 * C + i] : 0.f;
-    }
-    for (int i = t; i < IMG * Mp; i += 256) smid[i] = 0.f;
-    __syncthreads();
-
-    // ---- layer 1 ------------------------------------------------------------------------------------------------------
-    const int P = 256 / TM;
-    const int tx = t % TM, ty = t / TM;
-    const int Cp = ((C / 4 + P - 1) / P) * 4;                    // channels per partition (C % 8 == 0)
-    const int cbeg = min(C, ty * Cp), cend = min(C, cbeg + Cp);
-    for (int mb = 0; mb < M; mb += TM) {
-        const int m = mb + tx;
-        float acc[IMG];
+    const int P = 256 / TJ;
+    const int jx = t % TJ, kp = t / TJ;
+    const int j = j0 + jx;
+    const bool vec = (K & 3) == 0;
+    float acc[IMG];
 #pragma unroll
-        for (int i = 0; i < IMG; ++i) acc[i] = 0.f;
-        if (m < M) {
-            const float* wr = w1 + (size_t)m * C;
-            for (int c = cbeg; c < cend; c += 4) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + c);
-#pragma unroll
-                for (int i = 0; i < IMG; ++i) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(smean + i * C + c);
-                    acc[i] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
-                }
-            }
+    for (int i = 0; i < IMG; ++i) acc[i] = 0.f;
+    for (int kc = 0; kc < K; kc += KC) {
+        const int kn = min(KC, K - kc);
+        if (kc > 0) __syncthreads();
+        for (int i = t; i < IMG * kn; i += 256) {
+            const int img = i / kn, k = i - img * kn;
+            sin[img][k] = n0 + img < N ? in[(size_t)(n0 + img) * K + kc + k] : 0.f;
         }
-        if (P > 1) {
+        __syncthreads();
+        if (j < J) {
+            const float* wr = w + (size_t)j * K + kc;
+            if (vec) {
+                const int kper = ((kn / 4 + P - 1) / P) * 4;
+                const int kb = min(kn, kp * kper), ke = min(kn, kb + kper);
+                for (int k = kb; k < ke; k += 4) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-            for (int i = 0; i < IMG; ++i) spart[(ty * IMG + i) * TM + tx] = acc[i];
-            __syncthreads();
-            for (int j = t; j < IMG * TM; j += 256) {
-                const int i = j / TM, r = j % TM;
-                if (mb + r < M) {
-                    float a = b1[mb + r];
-                    for (int q = 0; q < P; ++q) a += spart[(q * IMG + i) * TM + r];
-                    smid[i * Mp + mb + r] = apply_act(a, mid_act);
+                    for (int i = 0; i < IMG; ++i) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(&sin[i][k]);
+                        acc[i] += wv[0] * v[0] + wv[1] * v[1] + wv[2] * v[2] + wv[3] * v[3];
+                    }
+                }
+            } else {
+                const int kper = (kn + P - 1) / P;
+                const int kb = min(kn, kp * kper), ke = min(kn, kb + kper);
+                for (int k = kb; k < ke; ++k) {
+                    const float wv = wr[k];
+#pragma unroll
+                    for (int i = 0; i < IMG; ++i) acc[i] += wv * sin[i][k];
                 }
             }
-            __syncthreads();
-        } else if (m < M) {
-            const float bias = b1[m];
-#pragma unroll
-            for (int i = 0; i < IMG; ++i) smid[i * Mp + m] = apply_act(acc[i] + bias, mid_act);
         }
     }
+#pragma unroll
+    for (int i = 0; i < IMG; ++i) spart[(kp * IMG + i) * TJ + jx] = acc[i];
     __syncthreads();
-
-    // ---- layer 2 ------------------------------------------------------------------------------------------------------
-    for (int c = t; c < C; c += 256) {
-        float acc[IMG];
-        const float bias = b2[c];
-#pragma unroll
-        for (int i = 0; i < IMG; ++i) acc[i] = bias;
-        const float* wr = w2 + (size_t)c * M;
-        if ((M & 3) == 0) {
-            for (int m = 0; m < M; m += 4) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + m);
-#pragma unroll
-                for (int i = 0; i < IMG; ++i) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(smid + i * Mp + m);
-                    acc[i] += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
-                }
-            }
-        } else {
-            for (int m = 0; m < M; ++m) {
-                const float w = wr[m];
-#pragma unroll
-                for (int i = 0; i < IMG; ++i) acc[i] += w * smid[i * Mp + m];
-            }
+    for (int o = t; o < IMG * TJ; o += 256) {
+        const int i = o / TJ, r = o - i * TJ;
+        if (j0 + r < J && n0 + i < N) {
+            float a = bias[j0 + r];
+            for (int q = 0; q < P; ++q) a += spart[(q * IMG + i) * TJ + r];
+            out[(size_t)(n0 + i) * J + j0 + r] = apply_act(a, act);
         }
-#pragma unroll
-        for (int i = 0; i < IMG; ++i)
-            if (n0 + i < N) gate[(size_t)(n0 + i) * C + c] = apply_act(acc[i], out_act);
     }
 }
 

@@ -867,26 +867,23 @@ int pcv_se_squeeze(pcv_ctx* ctx, const void* x, float* mean, int N, int HW, int 
     return PCV_OK;
 }
 
+static void launch_se_fc(const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act,
+                         hipStream_t st) {
+    int TJ = K >= 512 ? 32 : K >= 128 ? 64 : 256;               // long rows: split K over more threads of the block
+    while (TJ > 8 && TJ / 2 >= J) TJ /= 2;                      // few output rows: do not leave row slots idle
+    dim3 grid((unsigned)((N + 7) / 8), (unsigned)((J + TJ - 1) / TJ));
+    se_fc_kernel<<<grid, 256, 0, st>>>(in, w, b, out, N, K, J, TJ, act);
+}
+
 int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float* b1, const float* w2, const float* b2,
-                  float* gate, int N, int C, int M, int mid_act, int out_act, void* stream) {
+                  float* mid, float* gate, int N, int C, int M, int mid_act, int out_act, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
-    if (!mean || !w1 || !b1 || !w2 || !b2 || !gate || N <= 0 || C <= 0 || M <= 0)
+    if (!mean || !w1 || !b1 || !w2 || !b2 || !mid || !gate || N <= 0 || C <= 0 || M <= 0)
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: bad argument");
-    if (C % 8 != 0 || C > 8192 || M > 8192)
-        return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: C must be a multiple of 8, C and M at most 8192");
-    int TM = 8;
-    while (TM < M && TM < 256) TM *= 2;
-    const int img = C <= 1024 ? 8 : C <= 2048 ? 4 : C <= 4096 ? 2 : 1;       // [img][C] fp32 means stay within 32 KB of LDS
-    const int Mp = (M + 3) & ~3;
-    const size_t lds = ((size_t)img * C + (size_t)img * Mp + (size_t)256 * img) * sizeof(float);
-    if (lds > 64 * 1024) return fail(ctx, PCV_ERR_INVALID, "pcv_se_excite: C + M too large");
-    const int grid = (N + img - 1) / img;
     hipStream_t st = (hipStream_t)stream;
-    if (img == 8) se_excite_kernel<8><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
-    else if (img == 4) se_excite_kernel<4><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
-    else if (img == 2) se_excite_kernel<2><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
-    else se_excite_kernel<1><<<grid, 256, lds, st>>>(mean, w1, b1, w2, b2, gate, N, C, M, TM, mid_act, out_act);
+    launch_se_fc(mean, w1, b1, mid, N, C, M, mid_act, st);
+    launch_se_fc(mid, w2, b2, gate, N, M, C, out_act, st);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

@@ -311,8 +311,9 @@ def se_forward(x: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int, residual: NH
     gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.device)
     _lib.check(L.pcv_se_squeeze(ctx, _ptr(x.t), _ptr(mean), x.N, x.H * x.W, x.C, code, st), ctx)
     M = w1.shape[0]
-    _lib.check(L.pcv_se_excite(ctx, _ptr(mean), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(gate), x.N, x.C, M, mid_act,
-                               out_act, st), ctx)
+    mid = torch.empty((x.N, M), dtype=torch.float32, device=x.device)
+    _lib.check(L.pcv_se_excite(ctx, _ptr(mean), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mid), _ptr(gate), x.N, x.C, M,
+                               mid_act, out_act, st), ctx)
     y = torch.empty_like(x.t)
     if residual is not None and (residual.t.shape != x.t.shape or residual.dtype != x.dtype):
         raise RuntimeError("SE residual shape/dtype mismatch")
