@@ -135,6 +135,12 @@ int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float*
 int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y,
                  int N, int HW, int C, int post_act, int dtype, void* stream);
 
+/* y[rows,C] = act(x * scale[c] + shift[c]): the BatchNorm2d + activation a PreConvBlock applies BEFORE its convolution
+ * (conv.py:776-779) and PreResActivation (preresnet.py:199-222), for the places where it cannot ride in the producing
+ * convolution's epilogue (the unit input, which the skip path needs un-activated). rows = N*H*W. */
+int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C,
+               int act, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

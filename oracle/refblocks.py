@@ -6,14 +6,16 @@
     (see oracle/refnet.py). Reference lines: common/conv.py:204-543 (ConvBlock and factories), common/att.py:94-105
     (SEBlock), resnet.py:143-263 (ResUnit, ResInitBlock), mobilenetv2.py:16-71 (LinearBottleneck), resnext.py:17-116
     (ResNeXtUnit), seresnet.py:17-72 (SEResUnit), mobilenetv3.py:18-93 (MobileNetV3Unit),
-    efficientnet.py:58-239 (EffiDwsConvUnit, EffiInvResUnit, EffiInitBlock).
+    efficientnet.py:58-239 (EffiDwsConvUnit, EffiInvResUnit, EffiInitBlock), conv.py:652-810 (PreConvBlock),
+    preresnet.py:109-222 (PreResUnit, PreResInitBlock, PreResActivation).
 """
 
 __all__ = ['block_forward']
 
 import torch
 import torch.nn.functional as F
-from .refnet import Quant, conv_block, se_block, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit
+from .refnet import (Quant, conv_block, se_block, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit, bn_act,
+                     pre_conv_chain, preres_unit, preres_init_block)
 
 _KSIZE = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv5x5_block": (5, 2), "conv7x7_block": (7, 3),
           "dwconv3x3_block": (3, 1), "dwconv5x5_block": (5, 2)}
@@ -76,6 +78,15 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
             return effi_dws_unit(sd, "", x, q, kw["tf_mode"], kw["bn_eps"], residual_ok=(kw["stride"] == 1))
         if kind == "EffiInvResUnit":
             return effi_inv_res_unit(sd, "", x, q, kw["stride"], kw["tf_mode"], kw["bn_eps"])
+        if kind in ("pre_conv3x3_block", "pre_conv1x1_block"):
+            # PreConvBlock.forward, conv.py:776-786 (return_preact=False)
+            return pre_conv_chain(sd, [""], [kw.get("stride", 1)], bn_act(sd, "bn.", x, q), q)
+        if kind == "PreResUnit":
+            return preres_unit(sd, "", x, kw["stride"], kw["bottleneck"], kw["conv1_stride"], q)
+        if kind == "PreResInitBlock":
+            return preres_init_block(sd, "", x, q)
+        if kind == "PreResActivation":
+            return bn_act(sd, "bn.", x, q)
         if kind == "ResInitBlock":
             y = conv_block(sd, "conv.", x, stride=2, padding=3, q=q)
             return F.max_pool2d(y, kernel_size=3, stride=2, padding=1)

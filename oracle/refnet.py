@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -372,6 +372,94 @@ def mobilenetv3_forward(sd, x, version="large", q=None, taps=None):
     return x.view(x.size(0), -1)
 
 
+def bn_act(sd, prefix, x, q=None, act="relu", eps=1e-5):
+    """BatchNorm2d(eval) + activation as a stand-alone pass (PreConvBlock's front half, conv.py:776-779; PreResActivation,
+    preresnet.py:219-222): one rounding point when the GPU path runs it as its own launch."""
+    q = q or Quant(None)
+    if q.on:
+        scale, shift = fold_bn(sd, prefix, eps)
+        y = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.batch_norm(x, sd[prefix + "running_mean"], sd[prefix + "running_var"], sd[prefix + "weight"],
+                         sd[prefix + "bias"], False, 0.0, eps)
+    return q.r(_act(y, act))
+
+
+def pre_conv_chain(sd, prefixes, strides, a, q=None, residual=None, eps=1e-5):
+    """A run of PreConvBlocks (conv.py:776-786) whose first pre-activation has already been applied to `a`: block i's
+    Conv2d, then block i+1's BatchNorm + ReLU. The GPU path fuses exactly that pair into one launch, so in the
+    quantisation-matched mode the value is rounded once per pair; the skip add joins the last convolution."""
+    q = q or Quant(None)
+    for i, p in enumerate(prefixes):
+        w = sd[p + "conv.weight"].float()
+        b = sd.get(p + "conv.bias", None)
+        y = F.conv2d(a, q.r(w), b.float() if b is not None else None, strides[i], w.shape[-1] // 2)
+        if i + 1 < len(prefixes):
+            nb = prefixes[i + 1] + "bn."
+            if q.on:
+                scale, shift = fold_bn(sd, nb, eps)
+                y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            else:
+                y = F.batch_norm(y, sd[nb + "running_mean"], sd[nb + "running_var"], sd[nb + "weight"], sd[nb + "bias"],
+                                 False, 0.0, eps)
+            a = q.r(F.relu(y))
+        else:
+            if residual is not None:
+                y = y + residual
+            a = q.r(y)
+    return a
+
+
+def preres_unit(sd, p, x, stride, bottleneck, conv1_stride, q=None):
+    """PreResUnit.forward (preresnet.py:157-164) over PreResBlock (:58-61) / PreResBottleneck (:102-106)."""
+    q = q or Quant(None)
+    if bottleneck:
+        names = ["conv1.", "conv2.", "conv3."]
+        strides = [stride if conv1_stride else 1, 1 if conv1_stride else stride, 1]
+    else:
+        names = ["conv1.", "conv2."]
+        strides = [stride, 1]
+    pre = bn_act(sd, p + "body.conv1.bn.", x, q)
+    identity = x
+    if (p + "identity_conv.weight") in sd:
+        b = sd.get(p + "identity_conv.bias", None)
+        identity = q.r(F.conv2d(pre, q.r(sd[p + "identity_conv.weight"].float()), b.float() if b is not None else None, stride))
+    return pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q, residual=identity)
+
+
+def preres_init_block(sd, p, x, q=None):
+    """PreResInitBlock.forward (preresnet.py:190-196): conv7x7/2 -> BN -> ReLU -> MaxPool(3,2,1); conv/bn live on the block."""
+    q = q or Quant(None)
+    w = sd[p + "conv.weight"].float()
+    y = F.conv2d(x, q.r(w), None, 2, 3)
+    if q.on:
+        scale, shift = fold_bn(sd, p + "bn.")
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.batch_norm(y, sd[p + "bn.running_mean"], sd[p + "bn.running_var"], sd[p + "bn.weight"], sd[p + "bn.bias"],
+                         False, 0.0, 1e-5)
+    return F.max_pool2d(q.r(F.relu(y)), kernel_size=3, stride=2, padding=1)
+
+
+def preresnet_forward(sd, x, blocks=18, bottleneck=None, conv1_stride=True, q=None, taps=None):
+    """PreResNet.forward (preresnet.py:279-283); stage plan of get_preresnet (:320-369): the unit count per stage is read
+    from the state_dict."""
+    q = q or Quant(None)
+    if bottleneck is None:
+        bottleneck = blocks >= 50
+    x = preres_init_block(sd, "features.init_block.", q.r(x), q)
+    _tap(taps, "init_block", x)
+    for i in range(4):
+        j = 0
+        while ("features.stage{}.unit{}.body.conv1.conv.weight".format(i + 1, j + 1)) in sd:
+            stride = 1 if (i == 0) or (j != 0) else 2
+            x = preres_unit(sd, "features.stage{}.unit{}.".format(i + 1, j + 1), x, stride, bottleneck, conv1_stride, q)
+            j += 1
+        _tap(taps, "stage{}".format(i + 1), x)
+    x = bn_act(sd, "features.post_activ.bn.", x, q)
+    return _classifier(sd, x, q)
+
+
 def tf_same_pad(h, w, kernel_size, stride=1, dilation=1):
     """calc_tf_padding, efficientnet.py:27-55. Returned in F.pad order: the reference hands (pad_h//2, pad_h - pad_h//2,
     pad_w//2, pad_w - pad_w//2) to F.pad, which reads it as (left, right, top, bottom)."""
@@ -460,6 +548,17 @@ MODEL_ARCH = {
 for _v in ("small", "large"):
     for _t in ("w7d20", "wd2", "w3d4", "w1", "w5d4"):
         MODEL_ARCH["mobilenetv3_{}_{}".format(_v, _t)] = ("mobilenetv3", dict(version=_v))
+for _n, _kw in {"preresnet10": dict(blocks=10), "preresnet12": dict(blocks=12), "preresnet14": dict(blocks=14),
+                 "preresnetbc14b": dict(blocks=14, bottleneck=True, conv1_stride=False), "preresnet16": dict(blocks=16),
+                 "preresnet18": dict(blocks=18), "preresnet26": dict(blocks=26, bottleneck=False),
+                 "preresnetbc26b": dict(blocks=26, bottleneck=True, conv1_stride=False), "preresnet34": dict(blocks=34),
+                 "preresnetbc38b": dict(blocks=38, bottleneck=True, conv1_stride=False), "preresnet50": dict(blocks=50),
+                 "preresnet50b": dict(blocks=50, conv1_stride=False), "preresnet101": dict(blocks=101),
+                 "preresnet101b": dict(blocks=101, conv1_stride=False), "preresnet152": dict(blocks=152),
+                 "preresnet152b": dict(blocks=152, conv1_stride=False), "preresnet200": dict(blocks=200),
+                 "preresnet200b": dict(blocks=200, conv1_stride=False),
+                 "preresnet269b": dict(blocks=269, conv1_stride=False)}.items():
+    MODEL_ARCH[_n] = ("preresnet", _kw)
 for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
     MODEL_ARCH["efficientnet_" + _v] = ("efficientnet", dict(version=_v))
     for _t in ("b", "c"):
@@ -468,7 +567,8 @@ for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
 
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
            "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
-           "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward}
+           "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward,
+           "preresnet": preresnet_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

@@ -52,6 +52,7 @@ _SIGS = {
     "pcv_gemm_bias": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_se_squeeze": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "pcv_se_excite": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "pcv_bn_act": (_I, [_VP, _VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _VP]),
     "pcv_se_scale": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
 }
 

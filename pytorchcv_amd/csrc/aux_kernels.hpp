@@ -331,3 +331,24 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
         store8<DT>(y, (size_t)i * 8, v);
     }
 }
+
+// y = act(x * scale[c] + shift[c]): the BatchNorm + activation in FRONT of a convolution (PreConvBlock, conv.py:776-779;
+// PreResActivation, preresnet.py:199-222) when no producing convolution can take it as its epilogue. HBM-bound, 16 B/lane.
+template <int DT>
+__global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, void* __restrict__ y, long total8,
+                                                    int C, int act_code) {
+    const int C8 = C / 8;
+    const ActClamp act = make_act(act_code);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % C8) * 8;
+        float v[8], a[8], b[8];
+        load8<DT>(x, (size_t)i * 8, v);
+        load8<PCV_F32>(scale, c0, a);
+        load8<PCV_F32>(shift, c0, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * a[e] + b[e];
+        apply_act8(v, act);
+        store8<DT>(y, (size_t)i * 8, v);
+    }
+}

@@ -906,4 +906,22 @@ int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* res
     return PCV_OK;
 }
 
+int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int act,
+               int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype) || act < 0 || act > PCV_ACT_HSWISH)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_bn_act: bad argument (C must be a multiple of 8)");
+    const long total8 = rows * (C / 8);
+    long blocks = (total8 + 255) / 256;
+    const long cap = (long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
+    else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
+    else bn_act_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
 }  // extern "C"

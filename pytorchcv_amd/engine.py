@@ -5,7 +5,7 @@
 """
 
 __all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'from_nchw', 'to_nchw', 'ConvRunner',
-           'maxpool2d', 'avgpool2d', 'se_forward', 'act_code', 'boundary']
+           'BnActRunner', 'maxpool2d', 'avgpool2d', 'global_avgpool', 'se_forward', 'act_code', 'boundary']
 
 import os
 import ctypes
@@ -288,6 +288,55 @@ def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
     code = _CODE_OF_TORCH[x.dtype]
     _lib.check(_lib.lib().pcv_avgpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, code, code, _stream(x.device)), ctx)
     return NHWC(y, x.N, Ho, Wo, x.C)
+
+
+class BnActRunner(object):
+    """Eval-mode BatchNorm2d + activation as one elementwise launch (pcv_bn_act); scale/shift are folded once and refolded
+    when the parameters change (same cache rule as ConvRunner)."""
+    def __init__(self, bn):
+        self.bn = bn
+        self._key = None
+        self.scale = self.shift = None
+
+    def _state_key(self):
+        ts = (self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var)
+        return tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+
+    def prepare(self, x: NHWC):
+        key = self._state_key()
+        if key == self._key:
+            return
+        bn, dev = self.bn, x.device
+        if not isinstance(bn, nn.BatchNorm2d):
+            raise NotImplementedError("only BatchNorm2d folds to scale/shift, got {}".format(type(bn).__name__))
+        if bn.running_mean.device != dev:
+            raise RuntimeError("model parameters are on {} but the input is on {}".format(bn.running_mean.device, dev))
+        C = bn.num_features
+        L, ctx, st = _lib.lib(), _ctx(dev), _stream(dev)
+        g = bn.weight.detach().float().contiguous() if bn.weight is not None else torch.ones(C, device=dev)
+        b = bn.bias.detach().float().contiguous() if bn.bias is not None else torch.zeros(C, device=dev)
+        m = bn.running_mean.detach().float().contiguous()
+        v = bn.running_var.detach().float().contiguous()
+        scale = torch.empty(C, dtype=torch.float32, device=dev)
+        shift = torch.empty(C, dtype=torch.float32, device=dev)
+        _lib.check(L.pcv_bn_fold(ctx, C, _ptr(g), _ptr(b), _ptr(m), _ptr(v), ctypes.c_float(bn.eps), None, _ptr(scale),
+                                 _ptr(shift), st), ctx)
+        torch.cuda.current_stream(dev).synchronize()
+        self.scale, self.shift, self._key = scale, shift, key
+
+    def run(self, x: NHWC, act: int) -> NHWC:
+        if self.bn.training:
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        if not x.dense:
+            raise RuntimeError("BatchNorm + activation on a padded handle")
+        if x.C != self.bn.num_features:
+            raise RuntimeError("BatchNorm2d expects {} channels, got {}".format(self.bn.num_features, x.C))
+        self.prepare(x)
+        y = torch.empty_like(x.t)
+        ctx = _ctx(x.device)
+        _lib.check(_lib.lib().pcv_bn_act(ctx, _ptr(x.t), _ptr(self.scale), _ptr(self.shift), _ptr(y), x.N * x.H * x.W, x.C,
+                                         act, _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
+        return NHWC(y, x.N, x.H, x.W, x.C)
 
 
 def global_avgpool(x: NHWC) -> NHWC:

@@ -6,7 +6,8 @@
 """
 
 __all__ = ['conv1x1', 'conv3x3', 'depthwise_conv3x3', 'ConvBlock', 'conv1x1_block', 'conv3x3_block', 'conv5x5_block',
-           'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv']
+           'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv', 'PreConvBlock',
+           'pre_conv1x1_block', 'pre_conv3x3_block']
 
 import torch.nn as nn
 from .activ import lambda_relu, create_activation_layer
@@ -123,3 +124,79 @@ class DwsConvBlock(nn.Module):
 
 def dwsconv3x3_block(padding=1, **kwargs):
     return DwsConvBlock(kernel_size=3, padding=padding, **kwargs)
+
+
+class PreConvBlock(nn.Module):
+    """
+    BatchNorm + activation + convolution, the pre-activation order (reference PreConvBlock, conv.py:652-786): same
+    constructor, same attributes (`bn`, `activ`, `conv`), `forward` returns `x` or `(x, x_pre_activ)`.
+
+    On the MI355X path BN+activation is an epilogue wherever a convolution produces the tensor it applies to, so a chain
+    `PreConvBlock -> PreConvBlock` runs as `preact(x)` once (pcv_bn_act), then `conv_then(a, next_block)` per block: this
+    block's convolution with the NEXT block's BN+activation in its epilogue. `forward` is the unfused block for drop-in use.
+    """
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, bias=False,
+                 normalization=lambda_batchnorm2d(), activation=lambda_relu(), return_preact=False):
+        super(PreConvBlock, self).__init__()
+        self.normalize = (normalization is not None)
+        self.activate = (activation is not None)
+        self.return_preact = return_preact
+        if self.normalize:
+            self.bn = create_normalization_layer(normalization=normalization, num_features=in_channels)
+            if self.bn is None:
+                self.normalize = False
+            else:
+                assert isinstance(self.bn, nn.BatchNorm2d)
+        if self.activate:
+            self.activ = create_activation_layer(activation)
+            if self.activ is None:
+                self.activate = False
+            else:
+                assert isinstance(self.activ, nn.Module)
+        self.conv = nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride,
+                              padding=padding, dilation=dilation, bias=bias)
+        self._pcv_pre = None
+        self._pcv_runners = {}
+
+    def act_code(self):
+        return engine.act_code(self.activ) if self.activate else 0
+
+    def preact(self, a):
+        """activ(bn(a)) as its own launch."""
+        if not self.normalize:
+            raise NotImplementedError("PreConvBlock without normalization on the MI355X path")
+        if self._pcv_pre is None:
+            self._pcv_pre = engine.BnActRunner(self.bn)
+        return self._pcv_pre.run(a, self.act_code())
+
+    def conv_then(self, a, next_block=None, residual=None):
+        """This block's convolution applied to the already pre-activated `a`; `next_block`'s BN + activation (the
+        pre-activation of the following PreConvBlock) ride in the epilogue, or `residual` is added (last block of a unit)."""
+        key = id(next_block)
+        if key not in self._pcv_runners:
+            bn = next_block.bn if (next_block is not None and next_block.normalize) else None
+            self._pcv_runners[key] = engine.ConvRunner(self.conv, bn)
+        act = next_block.act_code() if next_block is not None else 0
+        return self._pcv_runners[key].run(a, act=act, residual=residual)
+
+    def _run(self, a):
+        pre = self.preact(a) if (self.normalize or self.activate) else a
+        y = self.conv_then(pre)
+        return (y, pre) if self.return_preact else y
+
+    def forward(self, x):
+        if isinstance(x, engine.NHWC):
+            return self._run(x)
+        out = self._run(engine.from_nchw(x, engine.compute_dtype_of(self)))
+        if self.return_preact:
+            return engine.to_nchw(out[0]), engine.to_nchw(out[1])
+        return engine.to_nchw(out)
+
+
+def pre_conv1x1_block(stride=1, padding=0, **kwargs):
+    return PreConvBlock(kernel_size=1, stride=stride, padding=padding, **kwargs)
+
+
+def pre_conv3x3_block(stride=1, padding=1, **kwargs):
+    return PreConvBlock(kernel_size=3, stride=stride, padding=padding, **kwargs)
+

@@ -98,7 +98,8 @@ def make_model(ref_models, name):
     mod = {"resnet18": "resnet", "resnet50": "resnet", "mobilenetv2_w1": "mobilenetv2",
            "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
            "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3",
-           "efficientnet_b0": "efficientnet", "efficientnet_b0b": "efficientnet"}[name]
+           "efficientnet_b0": "efficientnet", "efficientnet_b0b": "efficientnet",
+           "preresnet18": "preresnet", "preresnet50": "preresnet"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 
@@ -150,6 +151,7 @@ def build_block(case):
     from pytorchcv.models.efficientnet import EffiInitBlock, EffiDwsConvUnit, EffiInvResUnit
     from pytorchcv.models.common.activ import lambda_swish
     from pytorchcv.models.common.norm import lambda_batchnorm2d
+    from pytorchcv.models.preresnet import PreResUnit, PreResInitBlock, PreResActivation
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
@@ -160,7 +162,9 @@ def build_block(case):
             "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
             "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
             "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit,
-            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit}[kind]
+            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit,
+            "pre_conv3x3_block": C.pre_conv3x3_block, "pre_conv1x1_block": C.pre_conv1x1_block, "PreResUnit": PreResUnit,
+            "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation}[kind]
     return ctor(**kw).eval()
 
 

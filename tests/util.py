@@ -55,6 +55,7 @@ def build_block(case):
     from pytorchcv_amd.models.efficientnet import EffiInitBlock, EffiDwsConvUnit, EffiInvResUnit
     from pytorchcv_amd.models.common.activ import lambda_swish
     from pytorchcv_amd.models.common.norm import lambda_batchnorm2d
+    from pytorchcv_amd.models.preresnet import PreResUnit, PreResInitBlock, PreResActivation
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
@@ -65,7 +66,9 @@ def build_block(case):
             "conv7x7_block": C.conv7x7_block, "dwconv3x3_block": C.dwconv3x3_block, "dwconv5x5_block": C.dwconv5x5_block,
             "SEBlock": SEBlock, "ResUnit": ResUnit, "ResInitBlock": ResInitBlock, "LinearBottleneck": LinearBottleneck,
             "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit,
-            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit}[kind]
+            "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit,
+            "pre_conv3x3_block": C.pre_conv3x3_block, "pre_conv1x1_block": C.pre_conv1x1_block, "PreResUnit": PreResUnit,
+            "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation}[kind]
     return ctor(**kw).eval()
 
 
