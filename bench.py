@@ -221,6 +221,17 @@ def main():
         elapsed = float(t.item())
     assert bool(torch.isfinite(y).all())
 
+    # HBM traffic of the class from the PMC counters: cannot be read inside this process (rocprofv3 --pmc is its own run);
+    # the per-launch figure of the committed passes over this same command travels in profiles/pmc_traffic.json.
+    pmc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f).get(args.workload)
+        if pmc is not None and (pmc.get("dtype") != args.dtype or args.batch > 0):
+            pmc = None
+    except (OSError, ValueError):
+        pmc = None
+
     # per-launch HIP-event timing of the roofline kernel class (separate pass, not part of `value`)
     roof = None
     if rank == 0:
@@ -241,7 +252,11 @@ def main():
                         algorithmic_per_launch=(round(s["flops_per_launch"] / 1e9, 3) if bound == "mfma"
                                                 else round(s["bytes_per_launch"] / 1e6, 3)),
                         algorithmic_unit="GFLOP" if bound == "mfma" else "MB",
+                        algorithmic_mb_per_launch=round(s["bytes_per_launch"] / 1e6, 3),
                         per_shape={k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in s["per_shape"].items()})
+            if pmc is not None:
+                roof.update(traffic=pmc["traffic_mb_per_launch"], traffic_unit="MB per launch (HBM read + write)",
+                            traffic_source="profiles/pmc_traffic.json: " + pmc["note"])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -411,7 +411,8 @@ def pre_conv_chain(sd, prefixes, strides, a, q=None, residual=None, eps=1e-5):
 
 
 def preres_unit(sd, p, x, stride, bottleneck, conv1_stride, q=None):
-    """PreResUnit.forward (preresnet.py:157-164) over PreResBlock (:58-61) / PreResBottleneck (:102-106)."""
+    """PreResUnit.forward (preresnet.py:157-164) over PreResBlock (:58-61) / PreResBottleneck (:102-106); with an
+    `se.` sub-block in the state_dict it is SEPreResUnit.forward (sepreresnet.py:63-71): body -> SE -> + identity."""
     q = q or Quant(None)
     if bottleneck:
         names = ["conv1.", "conv2.", "conv3."]
@@ -424,6 +425,9 @@ def preres_unit(sd, p, x, stride, bottleneck, conv1_stride, q=None):
     if (p + "identity_conv.weight") in sd:
         b = sd.get(p + "identity_conv.bias", None)
         identity = q.r(F.conv2d(pre, q.r(sd[p + "identity_conv.weight"].float()), b.float() if b is not None else None, stride))
+    if (p + "se.conv1.weight") in sd:
+        y = pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q)
+        return se_block(sd, p + "se.", y, q=q, residual=identity)
     return pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q, residual=identity)
 
 
@@ -559,6 +563,8 @@ for _n, _kw in {"preresnet10": dict(blocks=10), "preresnet12": dict(blocks=12), 
                  "preresnet200b": dict(blocks=200, conv1_stride=False),
                  "preresnet269b": dict(blocks=269, conv1_stride=False)}.items():
     MODEL_ARCH[_n] = ("preresnet", _kw)
+    if _n != "preresnet269b":
+        MODEL_ARCH["se" + _n] = ("preresnet", _kw)          # SE-PreResNet: same trunk, `se.` blocks in the state_dict
 for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
     MODEL_ARCH["efficientnet_" + _v] = ("efficientnet", dict(version=_v))
     for _t in ("b", "c"):
