@@ -135,6 +135,15 @@ int pcv_se_excite(pcv_ctx* ctx, const float* mean, const float* w1, const float*
 int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* residual, void* y,
                  int N, int HW, int C, int post_act, int dtype, void* stream);
 
+/* Two chained 1x1 ConvBlocks in one launch: y1 = post_act1(act1(conv1(x)*s1+b1) + residual) - the last convolution of a
+ * bottleneck unit with its skip add (resnet.py:227-228) - and y2 = act2(conv2(y1)*s2+b2), the first convolution of the NEXT
+ * unit (resnet.py:106-109), without re-reading y1 from HBM. `pcv_conv1x1_pair_supported` tells whether a pair of descriptors is
+ * covered (currently 64 -> 256 -> 64 channels, stride 1, 16-bit); unsupported pairs are run as two pcv_conv2d_fused calls. */
+int pcv_conv1x1_pair_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2);
+int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
+                           const void* packed1, const float* scale1, const float* shift1, const void* residual, void* y1,
+                           const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
+
 /* y[rows,C] = act(x * scale[c] + shift[c]): the BatchNorm2d + activation a PreConvBlock applies BEFORE its convolution
  * (conv.py:776-779) and PreResActivation (preresnet.py:199-222), for the places where it cannot ride in the producing
  * convolution's epilogue (the unit input, which the skip path needs un-activated). rows = N*H*W. */

@@ -52,6 +52,9 @@ _SIGS = {
     "pcv_gemm_bias": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_se_squeeze": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "pcv_se_excite": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "pcv_conv1x1_pair_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
+    "pcv_conv1x1_pair_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                    _VP, _VP, _VP, _VP]),
     "pcv_bn_act": (_I, [_VP, _VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _VP]),
     "pcv_se_scale": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
 }

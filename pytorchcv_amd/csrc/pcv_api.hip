@@ -4,12 +4,14 @@
 #include <string>
 #include <vector>
 #include <cstring>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "conv3x3_inst.hpp"
 #include "stem_conv.hpp"
+#include "pair1x1.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 
@@ -335,6 +337,29 @@ static int enable_stem(pcv_ctx* ctx) {
     return PCV_OK;
 }
 
+static const int kPairLds = 3 * 64 * 64 * 2 + 64 * 1024;
+static int enable_pair(pcv_ctx* ctx) {
+    const void* fns[2] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16>),
+                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16>)};
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    return PCV_OK;
+}
+// Which (conv, next conv) pairs the fused kernel covers: 1x1/s1 64 -> 256 with residual, then 1x1/s1 256 -> 64, 16 bit.
+static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc& b) {
+    auto plain1x1 = [](const pcv_conv_desc& d) {
+        return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
+               d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
+               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W);
+    };
+    if (!plain1x1(a) || !plain1x1(b)) return "both convolutions must be plain 1x1 stride 1";
+    if (a.dtype != b.dtype || (a.dtype != PCV_BF16 && a.dtype != PCV_F16)) return "16-bit storage only";
+    if (a.N != b.N || a.H != b.H || a.W != b.W || a.Cout != b.Cin) return "shapes do not chain";
+    if (a.Cin != 64 || a.Cout != 256 || b.Cout != 64) return "only 64 -> 256 -> 64 is instantiated";
+    if (!a.has_residual || b.has_residual || b.post_act != PCV_ACT_NONE) return "first conv must carry the residual, second must not";
+    if ((long)a.N * a.H * a.W * 256 * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
+    return nullptr;
+}
+
 // launch helpers (templates need C++ linkage)
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
@@ -396,6 +421,7 @@ int pcv_create(pcv_ctx** out, int device) {
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
+    if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
         delete ctx;
@@ -902,6 +928,45 @@ int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* res
     if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
     else if (dtype == PCV_F16) se_scale_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
     else se_scale_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_conv1x1_pair_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2) {
+    return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr) ? 1 : 0;
+}
+
+int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x, const void* packed1,
+                           const float* scale1, const float* shift1, const void* residual, void* y1, const void* packed2,
+                           const float* scale2, const float* shift2, void* y2, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!d1 || !d2 || !x || !packed1 || !scale1 || !shift1 || !residual || !y1 || !packed2 || !scale2 || !shift2 || !y2)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: NULL argument");
+    if (const char* why = pair_unsupported(*d1, *d2)) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_fused: ") + why);
+    if (!aligned16(x) || !aligned16(packed1) || !aligned16(packed2) || !aligned16(residual) || !aligned16(y1) || !aligned16(y2))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: pointers must be 16-byte aligned");
+    ConvPlan P1, P2;
+    const char* why = plan_conv(*d1, P1, false);
+    if (!why) why = plan_conv(*d2, P2, false);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_fused: ") + why);
+    if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || P1.ngb != 1 || P2.ngb != 1)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
+    PairParams p;
+    std::memset(&p, 0, sizeof(p));
+    const long M = (long)d1->N * d1->H * d1->W;
+    p.x = x; p.res = residual; p.y1 = y1; p.y2 = y2;
+    p.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
+    p.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
+    p.x_bytes = (uint32_t)(M * 64 * 2); p.res_bytes = p.y1_bytes = (uint32_t)(M * 256 * 2); p.y2_bytes = (uint32_t)(M * 64 * 2);
+    p.w1_bytes = 256 * 64 * 2; p.w2_bytes = 64 * 256 * 2;
+    p.M = (int)M; p.nTiles = (int)((M + 63) / 64);
+    p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, ctx->num_cu);
+    hipStream_t st = (hipStream_t)stream;
+    if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16><<<grid, 256, kPairLds, st>>>(p);
+    else pair1x1_kernel<PCV_F16><<<grid, 256, kPairLds, st>>>(p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

@@ -68,6 +68,14 @@ class NHWC(object):
         return s if dim is None else s[dim]
 
 
+class _ShapeOnly(object):
+    """What ConvRunner.desc reads of its input, for a tensor that does not exist yet."""
+    __slots__ = ("N", "H", "W", "C", "dtype", "wpitch", "cpitch")
+
+    def __init__(self, N, H, W, C, dtype):
+        self.N, self.H, self.W, self.C, self.dtype, self.wpitch, self.cpitch = N, H, W, C, dtype, W, C
+
+
 def _stream(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -235,6 +243,31 @@ class ConvRunner(object):
         d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None)
         self.prepare(x, d)
         return self._launch(x, d, residual)
+
+    def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
+        """This convolution (+ residual, + post_act) and the 1x1 convolution `nxt` that consumes its output, as ONE launch
+        (pcv_conv1x1_pair_fused): returns (y1, y2), or None when the pair of shapes is not covered by the fused kernel."""
+        if residual is None or self.depthwise or nxt.depthwise or self.pad4 is not None or nxt.pad4 is not None:
+            return None
+        if (self.bn is not None and self.bn.training) or (nxt.bn is not None and nxt.bn.training):
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        c = self.conv
+        L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
+        d1 = self.desc(x, act, post_act, True)
+        d2 = nxt.desc(_ShapeOnly(x.N, x.H, x.W, c.out_channels, x.dtype), nxt_act, 0, False)
+        if not L.pcv_conv1x1_pair_supported(ctypes.byref(d1), ctypes.byref(d2)):
+            return None
+        if not residual.dense or residual.dtype != x.dtype or tuple(residual.t.shape) != (x.N, x.H, x.W, c.out_channels):
+            raise RuntimeError("residual shape/dtype mismatch")
+        t1 = torch.empty((x.N, x.H, x.W, c.out_channels), dtype=x.dtype, device=x.device)
+        t2 = torch.empty((x.N, x.H, x.W, nxt.conv.out_channels), dtype=x.dtype, device=x.device)
+        y1 = NHWC(t1, x.N, x.H, x.W, c.out_channels)
+        self.prepare(x, d1)
+        nxt.prepare(y1, d2)
+        _lib.check(L.pcv_conv1x1_pair_fused(ctx, ctypes.byref(d1), ctypes.byref(d2), _ptr(x.t), _ptr(self.packed),
+                                            _ptr(self.scale), _ptr(self.shift), _ptr(residual.t), _ptr(t1), _ptr(nxt.packed),
+                                            _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
+        return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels)
 
     def _launch(self, x: NHWC, d: ConvDesc, residual):
         c = self.conv

@@ -7,7 +7,7 @@
 
 __all__ = ['conv1x1', 'conv3x3', 'depthwise_conv3x3', 'ConvBlock', 'conv1x1_block', 'conv3x3_block', 'conv5x5_block',
            'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv', 'PreConvBlock',
-           'pre_conv1x1_block', 'pre_conv3x3_block']
+           'pre_conv1x1_block', 'pre_conv3x3_block', 'conv_block_pair']
 
 import torch.nn as nn
 from .activ import lambda_relu, create_activation_layer
@@ -76,6 +76,19 @@ class ConvBlock(nn.Module):
         pact = engine.act_code(post_act)
         return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact,
                                                                        pad4=pad4))
+
+
+def conv_block_pair(first, x, residual, post_act, second):
+    """`first` (with the unit's skip add and activation) and the ConvBlock `second` that consumes its output, as one fused
+    launch when the pair of shapes is covered (pcv_conv1x1_pair_fused): (y_first, y_second), else None."""
+    if not (isinstance(first, ConvBlock) and isinstance(second, ConvBlock) and isinstance(x, engine.NHWC)):
+        return None
+    for blk in (first, second):
+        if blk._pcv_runner is None:
+            blk._pcv_runner = engine.ConvRunner(blk.conv, blk.bn if blk.normalize else None, pad4=blk._pad4)
+    return first._pcv_runner.run_pair(x, residual, engine.act_code(first.activ) if first.activate else 0,
+                                      engine.act_code(post_act), second._pcv_runner,
+                                      engine.act_code(second.activ) if second.activate else 0)
 
 
 def conv1x1_block(padding=0, **kwargs):

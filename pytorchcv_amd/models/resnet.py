@@ -6,12 +6,12 @@
 
 __all__ = ['ResNet', 'resnet10', 'resnet12', 'resnet14', 'resnetbc14b', 'resnet16', 'resnet18', 'resnet26', 'resnetbc26b',
            'resnet34', 'resnetbc38b', 'resnet50', 'resnet50b', 'resnet101', 'resnet101b', 'resnet152', 'resnet152b',
-           'ResBlock', 'ResBottleneck', 'ResUnit', 'ResInitBlock', 'get_resnet']
+           'ResBlock', 'ResBottleneck', 'ResUnit', 'ResStage', 'ResInitBlock', 'get_resnet']
 
 import torch.nn as nn
 from .common.activ import lambda_relu
 from .common.norm import lambda_batchnorm2d
-from .common.conv import conv1x1_block, conv3x3_block, conv7x7_block
+from .common.conv import conv1x1_block, conv3x3_block, conv7x7_block, conv_block_pair
 from ._tail import MaxPool2dNHWC, AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
 
@@ -72,8 +72,36 @@ class ResUnit(nn.Module):
         identity = self.identity_conv(a) if self.resize_identity else a
         return self.body(a, residual=identity, post_act=self.activ)
 
+    def run_chained(self, a, conv1_out=None, next_unit=None):
+        """Stage-level execution of a bottleneck unit: `conv1_out` is this unit's first convolution when the previous unit
+        already produced it; with `next_unit`, the last convolution (+ skip add + ReLU) and the next unit's first
+        convolution go out as one launch whenever the pair is covered. Returns (unit output, next unit's conv1 output
+        or None)."""
+        identity = self.identity_conv(a) if self.resize_identity else a
+        body = self.body
+        y = body.conv2(conv1_out if conv1_out is not None else body.conv1(a))
+        if next_unit is not None:
+            pair = conv_block_pair(body.conv3, y, identity, self.activ, next_unit.body.conv1)
+            if pair is not None:
+                return pair
+        return body.conv3(y, residual=identity, post_act=self.activ), None
+
     def forward(self, x):
         return engine.boundary(self, x, self._run)
+
+
+class ResStage(nn.Sequential):
+    """A stage of units (plain nn.Sequential in the reference, resnet.py:297-313; same child names, same state_dict). On
+    the hot path consecutive bottleneck units are chained so that a unit's last 1x1 convolution and the next unit's
+    first one can share a launch."""
+    def forward(self, x):
+        units = list(self.children())
+        if not isinstance(x, engine.NHWC) or not all(isinstance(u, ResUnit) and isinstance(u.body, ResBottleneck) for u in units):
+            return super(ResStage, self).forward(x)
+        conv1_out = None
+        for i, unit in enumerate(units):
+            x, conv1_out = unit.run_chained(x, conv1_out, units[i + 1] if i + 1 < len(units) else None)
+        return x
 
 
 class ResInitBlock(nn.Module):
@@ -98,7 +126,7 @@ class ResNet(nn.Module):
         self.features.add_module("init_block", ResInitBlock(in_channels=in_channels, out_channels=init_block_channels))
         in_channels = init_block_channels
         for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
+            stage = ResStage()
             for j, out_channels in enumerate(channels_per_stage):
                 stride = 2 if (j == 0) and (i != 0) else 1
                 stage.add_module("unit{}".format(j + 1), ResUnit(in_channels=in_channels, out_channels=out_channels,
