@@ -42,13 +42,17 @@ template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int DT>
-__global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
+// PB: 16-pixel blocks per tile. PB = 4: 64-pixel tiles, one block per CU (needs > 256 registers); PB = 2: 32-pixel tiles,
+// half the accumulators, fits 256 registers and 44 KB of LDS -> two blocks (8 waves) per CU, which hides HBM latency better.
+template <int DT, int PB>
+__global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const PairParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int K1 = 64, C1 = 256, C2 = 64, P = 64;
-    constexpr int XB = P * K1 * 2;                                // 8 KB per x tile
+    constexpr int K1 = 64, C1 = 256, C2 = 64, P = 16 * PB;
+    constexpr int NXQ = PB / 2;                                   // x DMA pieces (8 pixel rows) per wave
+    constexpr int NIP = PB / 2;                                   // 32-channel output groups finished per wave
+    constexpr int XB = P * K1 * 2;                                // bytes per x tile
     typedef typename Mma<DT>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [x ring: 3 x 8 KB | reduction: 64 KB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [x ring: 3 tiles | reduction: 16 KB x PB]
     char* const red = smem + 3 * XB;
 
     const int tid = threadIdx.x;
@@ -82,35 +86,41 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
             a2[i][ks] = __builtin_bit_cast(frag, v2);
         }
     // epilogue constants: channels 64w + 32ip + 8fq + e (first GEMM), 32ip + 8fq + e (second GEMM)
-    float sc1[2][8], sf1[2][8], sc2[2][8], sf2[2][8];
+    float sc1[2][8], sf1[2][8], sc2[NIP][8], sf2[NIP][8];
 #pragma unroll
     for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c1 = 64 * wave + 32 * ip + 8 * fq + e, c2 = 32 * ip + 8 * fq + e;
+            const int c1 = 64 * wave + 32 * ip + 8 * fq + e;
             sc1[ip][e] = p.scale1[c1];
             sf1[ip][e] = p.shift1[c1];
-            sc2[ip][e] = p.scale2[c2];
-            sf2[ip][e] = p.shift2[c2];
+        }
+#pragma unroll
+    for (int k = 0; k < NIP; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c2 = 32 * ((wave / PB) * NIP + k) + 8 * fq + e;
+            sc2[k][e] = p.scale2[c2];
+            sf2[k][e] = p.shift2[c2];
         }
     const ActClamp act1 = make_act(p.act1), post1 = make_act(p.post1), act2 = make_act(p.act2);
 
     // ---- per-lane constant pieces of the addresses ----------------------------------------------------------------
     // x DMA: wave w moves pieces 2w, 2w+1 (8 pixel rows of 128 B each); lane L -> row 8pc + (L >> 3), LDS slot L & 7,
     // which must receive chunk (slot ^ swz(row)), swz(r) = (r >> 1) & 7 (conflict-free ds_read_b128 over 128-byte rows).
-    int xrow[2], xchunk[2];
+    int xrow[NXQ], xchunk[NXQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int pc = 2 * wave + q;
+    for (int q = 0; q < NXQ; ++q) {
+        const int pc = NXQ * wave + q;
         xrow[q] = 8 * pc + (lane >> 3);
         xchunk[q] = (lane & 7) ^ ((xrow[q] >> 1) & 7);
     }
     auto issue_x = [&](int t, int slot) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NXQ; ++q) {
             const long pix = (long)t * P + xrow[q];
             const uint32_t off = (t < p.nTiles && pix < p.M) ? (uint32_t)((pix * K1 + xchunk[q] * 8) * 2) : 0x80000000u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(smem + slot * XB + (2 * wave + q) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(smem + slot * XB + (NXQ * wave + q) * 1024), 16, off, 0, 0, 0);
         }
     };
     // residual / y1 element (ip, j): pixel 16j + fr, channels 64w + 32ip + 8fq .. +8
@@ -118,16 +128,16 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
         const long pix = (long)t * P + 16 * j + fr;
         return (t < p.nTiles && pix < p.M) ? (uint32_t)((pix * C1 + 64 * wave + 32 * ip + 8 * fq) * 2) : 0x80000000u;
     };
-    auto load_res = [&](int t, u32x4 (&r)[2][4]) {
+    auto load_res = [&](int t, u32x4 (&r)[2][PB]) {
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[ip][j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_c1(t, ip, j), 0, 0);
+            for (int j = 0; j < PB; ++j) r[ip][j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_c1(t, ip, j), 0, 0);
     };
     // B fragment of GEMM1: pixel row 16j + fr, chunk 4ks + fq
-    int xfrag[4][2];
+    int xfrag[PB][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PB; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int row = 16 * j + fr;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
     // The tile loop is unrolled by 3 = the x ring depth, so that the ring slot and the three residual register sets
     // (current, one ahead, two ahead) are compile-time constants: no register copies, whose operands would force a wait
     // for the prefetched loads at the end of every iteration.
-    u32x4 resr[3][2][4];
+    u32x4 resr[3][2][PB];
     issue_x(tile, 0);
     issue_x(tile + tstride, 1);
     load_res(tile, resr[0]);
@@ -149,29 +159,29 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
     auto step = [&](auto KC) -> bool {
         constexpr int slot = decltype(KC)::value;
         constexpr int slot2 = (slot + 2) % 3;
-        u32x4 (&resc)[2][4] = resr[slot];
-        // x(t) landed: all but the 20 youngest VMEM ops of this wave are done - those are the previous iteration's
-        // x(t+1) [2], residual(t+1) [8], y1 stores [8], y2 stores [2] (always issued, out of range when invalid).
-        if (!first) pair_wait_vmcnt<20>();
+        u32x4 (&resc)[2][PB] = resr[slot];
+        // x(t) landed: all but the 5 PB youngest VMEM ops of this wave are done - those are the previous iteration's
+        // x(t+2) [PB/2], residual(t+2) [2 PB], y1 stores [2 PB], y2 stores [PB/2] (always issued, out of range when invalid).
+        if (!first) pair_wait_vmcnt<5 * PB>();
         first = false;
         __syncthreads();
 
         // ---- GEMM1 ----------------------------------------------------------------------------------------------------
-        f32x4 acc[4][4];
+        f32x4 acc[4][PB];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* xb = smem + slot * XB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            frag b[4];
+            frag b[PB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const frag*>(xb + xfrag[j][ks]);
+            for (int j = 0; j < PB; ++j) b[j] = *reinterpret_cast<const frag*>(xb + xfrag[j][ks]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a1[i][ks], b[j], acc[i][j]);
+                for (int j = 0; j < PB; ++j) acc[i][j] = Mma<DT>::run(a1[i][ks], b[j], acc[i][j]);
         }
 
         // ---- prefetch two tiles ahead: x into the slot read in the previous iteration, residual into the free set ---------
@@ -179,11 +189,11 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
         load_res(tile + 2 * tstride, resr[slot2]);
 
         // ---- epilogue 1: BN, + residual, activation, round; the packs are GEMM2's B fragments ---------------------------
-        u32x4 o[2][4];
+        u32x4 o[2][PB];
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < PB; ++j) {
                 float v[8], r8[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -202,54 +212,59 @@ __global__ __launch_bounds__(256, 1) void pair1x1_kernel(const PairParams p) {
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(o[ip][j], y1rsrc, off_c1(tile, ip, j), 0, 0);
+            for (int j = 0; j < PB; ++j) __builtin_amdgcn_raw_buffer_store_b128(o[ip][j], y1rsrc, off_c1(tile, ip, j), 0, 0);
 
         // ---- GEMM2, this wave's K slice -----------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < PB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < PB; ++j)
                     acc[i][j] = Mma<DT>::run(a2[i][ip], __builtin_bit_cast(frag, o[ip][j]), acc[i][j]);
 
         // ---- the four K slices meet in LDS: [wave][i][j][lane] fp32x4 ------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<f32x4*>(red + (((wave * 4 + i) * 4 + j) * 64 + lane) * 16) = acc[i][j];
+            for (int j = 0; j < PB; ++j)
+                *reinterpret_cast<f32x4*>(red + (((wave * 4 + i) * PB + j) * 64 + lane) * 16) = acc[i][j];
         __syncthreads();
-        f32x4 z[4];
+        // wave w finishes pixel block jz for NIP of the two 32-channel output groups (PB = 4: one block, both groups;
+        // PB = 2: two waves share a pixel block, one group each)
+        const int jz = wave % PB, ip0 = (wave / PB) * NIP;
+        f32x4 z[2 * NIP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            z[i] = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + i) * 4 + wave) * 64 + lane) * 16);
+        for (int k = 0; k < 2 * NIP; ++k) {
+            const int i = 2 * ip0 + k;
+            z[k] = *reinterpret_cast<const f32x4*>(red + (((0 * 4 + i) * PB + jz) * 64 + lane) * 16);
 #pragma unroll
             for (int v = 1; v < 4; ++v) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(red + (((v * 4 + i) * 4 + wave) * 64 + lane) * 16);
-                z[i] += t;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(red + (((v * 4 + i) * PB + jz) * 64 + lane) * 16);
+                z[k] += t;
             }
         }
         __syncthreads();                                        // reduction buffer free for the next tile
 
-        // ---- epilogue 2: pixel block j = wave, channels 32ip + 8fq .. +8 -------------------------------------------------------
+        // ---- epilogue 2: pixel block jz, channels 32ip + 8fq .. +8 ---------------------------------------------------------------
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
+        for (int k = 0; k < NIP; ++k) {
+            const int ip = ip0 + k;
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = z[2 * ip][e] * sc2[ip][e] + sf2[ip][e];
-                v[4 + e] = z[2 * ip + 1][e] * sc2[ip][4 + e] + sf2[ip][4 + e];
+                v[e] = z[2 * k][e] * sc2[k][e] + sf2[k][e];
+                v[4 + e] = z[2 * k + 1][e] * sc2[k][4 + e] + sf2[k][4 + e];
             }
             apply_act8(v, act2);
             u32x4 q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-            const long pix = (long)tile * P + 16 * wave + fr;
+            const long pix = (long)tile * P + 16 * jz + fr;
             const uint32_t off = pix < p.M ? (uint32_t)((pix * C2 + 32 * ip + 8 * fq) * 2) : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b128(q, y2rsrc, off, 0, 0);
         }

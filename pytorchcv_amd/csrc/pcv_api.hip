@@ -34,6 +34,7 @@ struct pcv_ctx {
     int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
 
@@ -337,11 +338,20 @@ static int enable_stem(pcv_ctx* ctx) {
     return PCV_OK;
 }
 
-static const int kPairLds = 3 * 64 * 64 * 2 + 64 * 1024;
+static int pair_lds(int pb) { return 3 * 16 * pb * 64 * 2 + 16 * 1024 * pb; }      // x ring + reduction buffer
+static int g_pair_blocks_per_cu[2] = {1, 1};                                        // [PB == 4, PB == 2]
 static int enable_pair(pcv_ctx* ctx) {
-    const void* fns[2] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16>),
-                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16>)};
-    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kPairLds));
+    const void* fns[4] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 4>),
+                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 4>),
+                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 2>),
+                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 2>)};
+    for (int i = 0; i < 4; ++i) {
+        const int lds = pair_lds(i < 2 ? 4 : 2);
+        HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int nb = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, lds));
+        g_pair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
+    }
     return PCV_OK;
 }
 // Which (conv, next conv) pairs the fused kernel covers: 1x1/s1 64 -> 256 with residual, then 1x1/s1 256 -> 64, 16 bit.
@@ -444,6 +454,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "conv3_cfg") ctx->force_conv3_cfg = value;
     else if (k == "c3flags") ctx->conv3_flags = value;
     else if (k == "tile") ctx->force_tile = value;
+    else if (k == "pair_pb") ctx->pair_pb = value;
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
@@ -961,12 +972,18 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
     p.x_bytes = (uint32_t)(M * 64 * 2); p.res_bytes = p.y1_bytes = (uint32_t)(M * 256 * 2); p.y2_bytes = (uint32_t)(M * 64 * 2);
     p.w1_bytes = 256 * 64 * 2; p.w2_bytes = 64 * 256 * 2;
-    p.M = (int)M; p.nTiles = (int)((M + 63) / 64);
+    const int pb = ctx->pair_pb == 4 ? 4 : 2;
+    p.M = (int)M; p.nTiles = (int)((M + 16 * pb - 1) / (16 * pb));
     p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
-    const unsigned grid = (unsigned)std::min<long>(p.nTiles, ctx->num_cu);
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_blocks_per_cu[pb == 4 ? 0 : 1]);
     hipStream_t st = (hipStream_t)stream;
-    if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16><<<grid, 256, kPairLds, st>>>(p);
-    else pair1x1_kernel<PCV_F16><<<grid, 256, kPairLds, st>>>(p);
+    if (pb == 4) {
+        if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 4><<<grid, 256, pair_lds(4), st>>>(p);
+        else pair1x1_kernel<PCV_F16, 4><<<grid, 256, pair_lds(4), st>>>(p);
+    } else {
+        if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2><<<grid, 256, pair_lds(2), st>>>(p);
+        else pair1x1_kernel<PCV_F16, 2><<<grid, 256, pair_lds(2), st>>>(p);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

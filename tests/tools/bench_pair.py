@@ -25,8 +25,16 @@ def only1():
     return first(x, residual=r, post_act=relu)
 def fused():
     return conv_block_pair(first, x, r, relu, second)
-times = {"conv3+res": [], "separate": [], "fused": []}
-fns = {"conv3+res": only1, "separate": sep, "fused": fused}
+from pytorchcv_amd import _lib
+ctx = _lib.ctx_for(0)
+def tune(v):
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"pair_pb", v), ctx)
+def fused4():
+    tune(4); return fused()
+def fused2():
+    tune(2); return fused()
+times = {"conv3+res": [], "separate": [], "fused pb4": [], "fused pb2": []}
+fns = {"conv3+res": only1, "separate": sep, "fused pb4": fused4, "fused pb2": fused2}
 with torch.no_grad():
     for f in fns.values():
         f()
@@ -40,5 +48,4 @@ with torch.no_grad():
             e1.record(); torch.cuda.synchronize()
             times[k].append(e0.elapsed_time(e1) / 5 * 1e3)
 mb = N * H * H * (64 + 256 + 256 + 64) * 2 / 1e6
-print("  ".join("%s %.1f us" % (k, statistics.median(t)) for k, t in times.items()),
-      " fused moves %.0f MB -> %.2f TB/s" % (mb, mb / statistics.median(times["fused"]) / 1e6 * 1e6 / 1e6))
+print("  ".join("%s %.1f us" % (k, statistics.median(t)) for k, t in times.items()), " (fused moves %.0f MB)" % mb)
