@@ -217,13 +217,15 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
 // ---------------------------------------------------------------------------------------------------------
 // Kernel table
 // ---------------------------------------------------------------------------------------------------------
-enum TileCfg { TILE_C32 = 0, TILE_C64 = 1, TILE_C128 = 2, TILE_C256 = 3, TILE_COUNT = 4 };
+enum TileCfg { TILE_C32 = 0, TILE_C64 = 1, TILE_C128 = 2, TILE_C256 = 3, TILE_C64S = 4, TILE_C128S = 5, TILE_COUNT = 6 };
 struct TileInfo { int BM, BP, threads, lds; };
 static const TileInfo kTiles[TILE_COUNT] = {
     {32, 256, 256, 2 * (32 + 256) * 128},
     {64, 256, 256, 2 * (64 + 256) * 128},
     {128, 128, 256, 2 * (128 + 128) * 128},
     {256, 64, 256, 2 * (256 + 64) * 128},
+    {64, 128, 256, 2 * (64 + 128) * 128},      // 1x1 only
+    {128, 64, 256, 2 * (128 + 64) * 128},      // 1x1 only
 };
 typedef void (*igemm_fn)(const IgemmParams);
 
@@ -232,7 +234,10 @@ template <int DT, int KHW> static igemm_fn igemm_for_tile(int tile) {
         case TILE_C32: return igemm_conv_kernel<DT, DT, 2, 4, 1, 4, false, KHW>;
         case TILE_C64: return igemm_conv_kernel<DT, DT, 4, 4, 1, 4, false, KHW>;
         case TILE_C128: return igemm_conv_kernel<DT, DT, 4, 4, 2, 2, false, KHW>;
-        default: return igemm_conv_kernel<DT, DT, 4, 4, 4, 1, false, KHW>;
+        case TILE_C256: return igemm_conv_kernel<DT, DT, 4, 4, 4, 1, false, KHW>;
+        case TILE_C64S: if constexpr (KHW == 1) return igemm_conv_kernel<DT, DT, 4, 2, 1, 4, false, 1>; else return nullptr;
+        case TILE_C128S: if constexpr (KHW == 1) return igemm_conv_kernel<DT, DT, 4, 2, 2, 2, false, 1>; else return nullptr;
+        default: return nullptr;
     }
 }
 template <int DT> static igemm_fn igemm_for_taps(int tile, int khw) {
@@ -696,7 +701,6 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     else if (P.cout_blk <= 128) tile = TILE_C128;
     else if (P.cout_blk <= 256) tile = (d->kh * d->kw > 1) ? TILE_C128 : TILE_C256;   // 256x64 only pays for HBM-bound 1x1 (reads x once)
     else tile = TILE_C128;
-    if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !ragged && d->out_dtype == d->dtype) tile = ctx->force_tile;
     if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
     const bool special = ragged || d->out_dtype != d->dtype;
     int khw = 0;
@@ -704,6 +708,15 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         if (d->kh == 1 && d->kw == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0) khw = 1;
         else if (d->kh == 3 && d->kw == 3 && P.cin_blk % (8 * P.CE) == 0) khw = 9;
     }
+    if (khw == 1) {
+        // 1x1 reductions (many K-steps into few channels) run best on the half-height tiles (3 blocks per CU); the 256-channel
+        // tile only pays when the input is narrow (it reads x once) - tests/tools/sweep_1x1_tiles.py
+        if (tile == TILE_C64 && d->Cin >= 256) tile = TILE_C64S;
+        else if (tile == TILE_C128 && P.cout_blk <= 128 && d->Cin >= 512) tile = TILE_C128S;
+        else if (tile == TILE_C256 && d->Cin > 128) tile = TILE_C128;
+    }
+    if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !special && (ctx->force_tile < TILE_C64S || khw == 1))
+        tile = ctx->force_tile;
     igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, special, tile, khw);
     if (!fn) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: no kernel for this dtype combination");
     const TileInfo& T = kTiles[tile];
