@@ -144,6 +144,19 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
                            const void* packed1, const float* scale1, const float* shift1, const void* residual, void* y1,
                            const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
 
+/* A whole inverted-residual unit in one launch: [1x1 expand ConvBlock] -> depthwise 3x3 ConvBlock -> 1x1 project ConvBlock
+ * (+ skip add): LinearBottleneck.forward (mobilenetv2.py:62-71), MobileNetV3Unit without SE (mobilenetv3.py:82-93),
+ * DwsConvBlock (conv.py:612-615; d_exp == NULL). The expanded tensor stays on the CU. The descriptors and packed blobs are
+ * those of the three separate calls (pcv_conv_pack / pcv_dwconv_pack); `residual` belongs to d_proj (has_residual, post_act).
+ * `pcv_mbconv_supported` tells whether a triple is covered AND pays (16-bit, depthwise 3x3 pad 1 stride 1/2, <= 96 input and
+ * <= 32 output channels, output maps at least 24 wide - the large early maps where the expanded tensor dominates);
+ * anything else runs as the separate calls. */
+int pcv_mbconv_supported(const pcv_conv_desc* d_exp, const pcv_conv_desc* d_dw, const pcv_conv_desc* d_proj);
+int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_desc* d_dw, const pcv_conv_desc* d_proj,
+                     const void* x, const void* packed_exp, const float* scale_e, const float* shift_e,
+                     const void* packed_dw, const float* scale_d, const float* shift_d, const void* packed_proj,
+                     const float* scale_p, const float* shift_p, const void* residual, void* y, void* stream);
+
 /* y[rows,C] = act(x * scale[c] + shift[c]): the BatchNorm2d + activation a PreConvBlock applies BEFORE its convolution
  * (conv.py:776-779) and PreResActivation (preresnet.py:199-222), for the places where it cannot ride in the producing
  * convolution's epilogue (the unit input, which the skip path needs un-activated). rows = N*H*W. */

@@ -55,6 +55,9 @@ _SIGS = {
     "pcv_conv1x1_pair_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "pcv_conv1x1_pair_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                     _VP, _VP, _VP, _VP]),
+    "pcv_mbconv_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
+    "pcv_mbconv_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP,
+                              _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pcv_bn_act": (_I, [_VP, _VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _VP]),
     "pcv_se_scale": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
 }

@@ -12,6 +12,7 @@
 #include "conv3x3_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
+#include "mbconv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 
@@ -375,6 +376,66 @@ static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc&
     return nullptr;
 }
 
+// ---- fused inverted-residual unit (mbconv.hpp) ----------------------------------------------------------------------------
+typedef void (*mbconv_fn)(const MbParams);
+template <int DT, int RT> static mbconv_fn mbconv_for(int stride, bool expand) {
+    if (stride == 1) return expand ? mbconv_kernel<DT, 1, true, RT> : mbconv_kernel<DT, 1, false, RT>;
+    return expand ? mbconv_kernel<DT, 2, true, RT> : mbconv_kernel<DT, 2, false, RT>;
+}
+static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
+    if (dt == PCV_BF16) return nrowt <= 2 ? mbconv_for<PCV_BF16, 2>(stride, expand) : mbconv_for<PCV_BF16, 6>(stride, expand);
+    return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
+}
+static const int kMbMaxLds = 96 * 1024;
+static int mbconv_lds(int stride, int ka_x) {       // ka_x: K-steps of the resident x tile (0 without an expand convolution)
+    const int npt = stride == 1 ? 12 : 19, outpx = stride == 1 ? 128 : 64;
+    return (ka_x > 0 ? 1 : 2) * npt * 16 * 64 + outpx * 64 + ((npt * 16 + 15) & ~15) + ka_x * npt * 16 * 64;
+}
+static int enable_mbconv(pcv_ctx* ctx) {
+    for (int dt = PCV_BF16; dt <= PCV_F16; ++dt)
+        for (int s = 1; s <= 2; ++s)
+            for (int e = 0; e < 2; ++e)
+                for (int rt = 2; rt <= 6; rt += 4)
+                    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbconv(dt, s, e != 0, rt)),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMbMaxLds));
+    return PCV_OK;
+}
+// de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
+static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_desc& dd, const pcv_conv_desc& dp) {
+    auto plain1x1 = [](const pcv_conv_desc& d) {
+        return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
+               d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
+               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W);
+    };
+    if (dd.dtype != PCV_BF16 && dd.dtype != PCV_F16) return "16-bit storage only";
+    if (dd.kh != 3 || dd.kw != 3 || dd.dil_h != 1 || dd.dil_w != 1 || dd.pad_t != 1 || dd.pad_l != 1 || dd.pad_b != 1 ||
+        dd.pad_r != 1 || dd.stride_h != dd.stride_w || (dd.stride_h != 1 && dd.stride_h != 2) || dd.groups != dd.Cin ||
+        dd.Cin != dd.Cout || dd.has_residual || dd.out_dtype != dd.dtype || (dd.x_cpitch != 0 && dd.x_cpitch != dd.Cin) ||
+        (dd.x_wpitch != 0 && dd.x_wpitch != dd.W))
+        return "depthwise stage must be 3x3, pad 1, stride 1 or 2, no residual";
+    const int Cmid = dd.Cin;
+    if (Cmid % 8 != 0) return "expanded channels must be a multiple of 8";
+    if (!plain1x1(dp) || dp.dtype != dd.dtype || dp.Cin != Cmid || dp.Cout % 8 != 0 || dp.Cout > 96) return "project stage must be a plain 1x1 with at most 96 channels";
+    // measured (MobileNetV2, batch 512): the fused unit wins on the large maps (the expanded tensor is what costs) and loses on
+    // 14x14 and below / wide projections, where the three separate launches are cheap and this kernel is VALU-bound
+    if (dp.Cout > 32) return "fused unit only pays for narrow projections (<= 32 channels)";
+    const int Ho = (dd.H - 1) / dd.stride_h + 1, Wo = (dd.W - 1) / dd.stride_w + 1;
+    if (dp.N != dd.N || dp.H != Ho || dp.W != Wo) return "shapes do not chain";
+    if (Wo < 24 || Ho < 8) return "map too small for the fused unit to pay";
+    int ka = 0;
+    if (de) {
+        if (!plain1x1(*de) || de->dtype != dd.dtype || de->Cout != Cmid || de->Cin % 8 != 0 || de->has_residual ||
+            de->N != dd.N || de->H != dd.H || de->W != dd.W)
+            return "expand stage must be a plain 1x1 onto the depthwise input";
+        ka = (de->Cin + 31) / 32;
+        if (ka > 3) return "expand stage input wider than 96 channels";
+    }
+    if (mbconv_lds(dd.stride_h, ka) > kMbMaxLds) return "input tile does not fit the LDS budget";
+    const long cin = de ? de->Cin : Cmid;
+    if ((long)dd.N * dd.H * dd.W * cin * 2 >= (1L << 31) || (long)dd.N * Ho * Wo * dp.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
+    return nullptr;
+}
+
 // launch helpers (templates need C++ linkage)
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
@@ -437,6 +498,7 @@ int pcv_create(pcv_ctx** out, int device) {
     if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
+    if (rc == PCV_OK) rc = enable_mbconv(ctx);
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
         delete ctx;
@@ -997,6 +1059,61 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2><<<grid, 256, pair_lds(2), st>>>(p);
         else pair1x1_kernel<PCV_F16, 2><<<grid, 256, pair_lds(2), st>>>(p);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_mbconv_supported(const pcv_conv_desc* d_exp, const pcv_conv_desc* d_dw, const pcv_conv_desc* d_proj) {
+    return (d_dw && d_proj && mbconv_unsupported(d_exp, *d_dw, *d_proj) == nullptr) ? 1 : 0;
+}
+
+int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_desc* d_dw, const pcv_conv_desc* d_proj,
+                     const void* x, const void* packed_exp, const float* scale_e, const float* shift_e, const void* packed_dw,
+                     const float* scale_d, const float* shift_d, const void* packed_proj, const float* scale_p,
+                     const float* shift_p, const void* residual, void* y, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!d_dw || !d_proj || !x || !packed_dw || !scale_d || !shift_d || !packed_proj || !scale_p || !shift_p || !y ||
+        (d_exp && (!packed_exp || !scale_e || !shift_e)))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: NULL argument");
+    if (const char* why = mbconv_unsupported(d_exp, *d_dw, *d_proj)) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_mbconv_fused: ") + why);
+    if (d_proj->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: has_residual but residual is NULL");
+    if (!aligned16(x) || !aligned16(packed_dw) || !aligned16(packed_proj) || !aligned16(y) || (d_exp && !aligned16(packed_exp)) ||
+        (residual && !aligned16(residual)) || !aligned16(scale_d) || !aligned16(shift_d) || !aligned16(scale_p) || !aligned16(shift_p) ||
+        (d_exp && (!aligned16(scale_e) || !aligned16(shift_e))))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: pointers must be 16-byte aligned");
+    ConvPlan Pe, Pp;
+    const char* why = d_exp ? plan_conv(*d_exp, Pe, false) : nullptr;
+    if (!why) why = plan_conv(*d_proj, Pp, false);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_mbconv_fused: ") + why);
+    if (Pp.ngb != 1 || (d_exp && Pe.ngb != 1)) return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
+    MbParams p;
+    std::memset(&p, 0, sizeof(p));
+    const int S = d_dw->stride_h;
+    p.x = x; p.res = d_proj->has_residual ? residual : nullptr; p.y = y;
+    p.w_exp = d_exp ? static_cast<const char*>(packed_exp) + Pe.ktab_bytes : nullptr;
+    p.w_dw = packed_dw;
+    p.w_proj = static_cast<const char*>(packed_proj) + Pp.ktab_bytes;
+    p.scale_e = scale_e; p.shift_e = shift_e; p.scale_d = scale_d; p.shift_d = shift_d; p.scale_p = scale_p; p.shift_p = shift_p;
+    p.N = d_dw->N; p.H = d_dw->H; p.W = d_dw->W; p.Cmid = d_dw->Cin; p.Cin = d_exp ? d_exp->Cin : p.Cmid; p.Cout = d_proj->Cout;
+    p.Ho = (p.H - 1) / S + 1; p.Wo = (p.W - 1) / S + 1;
+    p.x_bytes = (uint32_t)((long)p.N * p.H * p.W * p.Cin * 2);
+    p.y_bytes = (uint32_t)((long)p.N * p.Ho * p.Wo * p.Cout * 2);
+    p.wexp_bytes = d_exp ? (uint32_t)Pe.w_bytes : 0;
+    p.wdw_bytes = (uint32_t)(9 * p.Cmid * 2);
+    p.wproj_bytes = (uint32_t)Pp.w_bytes;
+    p.Kpad1 = d_exp ? Pe.Kpad : 0; p.Kpad2 = Pp.Kpad;
+    p.ka = d_exp ? (p.Cin + 31) / 32 : 0;
+    p.nChunks = (p.Cmid + 31) / 32;
+    p.nRowT = Pp.wrows / 16;
+    const int TH = S == 1 ? 8 : 4;
+    p.tilesH = (p.Ho + TH - 1) / TH; p.tilesW = (p.Wo + 15) / 16;
+    p.nTiles = p.N * p.tilesH * p.tilesW;
+    p.act_e = d_exp ? d_exp->act : 0; p.act_d = d_dw->act; p.act_p = d_proj->act; p.post = d_proj->post_act;
+    if (p.nRowT > 6 || (d_exp && p.Kpad1 < 32 * p.ka) || p.Kpad2 < 32 * p.nChunks)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
+    const int lds = mbconv_lds(S, p.ka);
+    hipLaunchKernelGGL(pick_mbconv(d_dw->dtype, S, d_exp != nullptr, p.nRowT), dim3((unsigned)p.nTiles), dim3(256), lds, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

@@ -323,6 +323,56 @@ def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
     return NHWC(y, x.N, Ho, Wo, x.C)
 
 
+def mbconv_fused(exp, exp_act: int, dw, dw_act: int, proj, proj_act: int, x: NHWC, residual, post_act: int):
+    """[expand 1x1 ->] depthwise 3x3 -> project 1x1 (+ residual) as ONE launch (pcv_mbconv_fused); `exp`, `dw`, `proj` are
+    the ConvRunners of the three blocks (`exp` may be None). Returns the unit output, or None when the triple of shapes is
+    not covered by the fused kernel (the caller then issues the separate launches)."""
+    if not x.dense or not dw.depthwise or proj.depthwise or (exp is not None and exp.depthwise):
+        return None
+    if any(r is not None and r.pad4 is not None for r in (exp, dw, proj)):
+        return None
+    for r in (exp, dw, proj):
+        if r is not None and r.bn is not None and r.bn.training:
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+    L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
+    cur = x
+    d_exp = None
+    if exp is not None:
+        d_exp = exp.desc(x, exp_act, 0, False)
+        cur = _ShapeOnly(x.N, x.H, x.W, exp.conv.out_channels, x.dtype)
+    d_dw = dw.desc(cur, dw_act, 0, False)
+    Ho = (cur.H + d_dw.pad_t + d_dw.pad_b - d_dw.dil_h * (d_dw.kh - 1) - 1) // d_dw.stride_h + 1
+    Wo = (cur.W + d_dw.pad_l + d_dw.pad_r - d_dw.dil_w * (d_dw.kw - 1) - 1) // d_dw.stride_w + 1
+    mid = _ShapeOnly(x.N, Ho, Wo, dw.conv.out_channels, x.dtype)
+    d_proj = proj.desc(mid, proj_act, post_act, residual is not None)
+    if not L.pcv_mbconv_supported(ctypes.byref(d_exp) if d_exp is not None else None, ctypes.byref(d_dw), ctypes.byref(d_proj)):
+        return None
+    Cout = proj.conv.out_channels
+    if residual is not None and (not residual.dense or residual.dtype != x.dtype or
+                                 tuple(residual.t.shape) != (x.N, Ho, Wo, Cout)):
+        raise RuntimeError("residual shape/dtype mismatch")
+    # weights / BN constants are packed through the runners' own caches (dense handles of the right shape and dtype)
+    if exp is not None:
+        exp.prepare(x, d_exp)
+    dw.prepare(_PrepHandle(cur, x.device), d_dw)
+    proj.prepare(_PrepHandle(mid, x.device), d_proj)
+    y = torch.empty((x.N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(L.pcv_mbconv_fused(ctx, ctypes.byref(d_exp) if d_exp is not None else None, ctypes.byref(d_dw), ctypes.byref(d_proj),
+                                  _ptr(x.t), _ptr(exp.packed) if exp is not None else None,
+                                  _ptr(exp.scale) if exp is not None else None, _ptr(exp.shift) if exp is not None else None,
+                                  _ptr(dw.packed), _ptr(dw.scale), _ptr(dw.shift), _ptr(proj.packed), _ptr(proj.scale),
+                                  _ptr(proj.shift), _ptr(residual.t) if residual is not None else None, _ptr(y), st), ctx)
+    return NHWC(y, x.N, Ho, Wo, Cout)
+
+
+class _PrepHandle(object):
+    """dtype / cpitch / device of a tensor that is never materialised, for ConvRunner.prepare."""
+    __slots__ = ("dtype", "cpitch", "device")
+
+    def __init__(self, shape_only, device):
+        self.dtype, self.cpitch, self.device = shape_only.dtype, shape_only.cpitch, device
+
+
 class BnActRunner(object):
     """Eval-mode BatchNorm2d + activation as one elementwise launch (pcv_bn_act); scale/shift are folded once and refolded
     when the parameters change (same cache rule as ConvRunner)."""

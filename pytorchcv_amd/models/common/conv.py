@@ -7,7 +7,7 @@
 
 __all__ = ['conv1x1', 'conv3x3', 'depthwise_conv3x3', 'ConvBlock', 'conv1x1_block', 'conv3x3_block', 'conv5x5_block',
            'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv', 'PreConvBlock',
-           'pre_conv1x1_block', 'pre_conv3x3_block', 'conv_block_pair']
+           'pre_conv1x1_block', 'pre_conv3x3_block', 'conv_block_pair', 'mbconv_chain']
 
 import torch.nn as nn
 from .activ import lambda_relu, create_activation_layer
@@ -91,6 +91,23 @@ def conv_block_pair(first, x, residual, post_act, second):
                                       engine.act_code(second.activ) if second.activate else 0)
 
 
+def mbconv_chain(exp_block, dw_block, proj_block, x, residual=None, post_act=None):
+    """[expand ConvBlock ->] depthwise ConvBlock -> project ConvBlock (+ skip add) as one fused launch when the shapes are
+    covered (pcv_mbconv_fused), else None: the caller then runs the blocks one by one."""
+    blocks = [b for b in (exp_block, dw_block, proj_block) if b is not None]
+    if not isinstance(x, engine.NHWC) or not all(isinstance(b, ConvBlock) for b in blocks):
+        return None
+    for blk in blocks:
+        if blk._pcv_runner is None:
+            blk._pcv_runner = engine.ConvRunner(blk.conv, blk.bn if blk.normalize else None, pad4=blk._pad4)
+
+    def code(blk):
+        return engine.act_code(blk.activ) if blk.activate else 0
+    return engine.mbconv_fused(exp_block._pcv_runner if exp_block is not None else None,
+                               code(exp_block) if exp_block is not None else 0, dw_block._pcv_runner, code(dw_block),
+                               proj_block._pcv_runner, code(proj_block), x, residual, engine.act_code(post_act))
+
+
 def conv1x1_block(padding=0, **kwargs):
     return ConvBlock(kernel_size=1, padding=padding, **kwargs)
 
@@ -131,8 +148,12 @@ class DwsConvBlock(nn.Module):
         self.pw_conv = conv1x1_block(in_channels=in_channels, out_channels=out_channels, bias=bias,
                                      normalization=pw_normalization, activation=pw_activation)
 
+    def _run(self, a):
+        y = mbconv_chain(None, self.dw_conv, self.pw_conv, a)
+        return y if y is not None else self.pw_conv(self.dw_conv(a))
+
     def forward(self, x):
-        return engine.boundary(self, x, lambda a: self.pw_conv(self.dw_conv(a)))
+        return engine.boundary(self, x, self._run)
 
 
 def dwsconv3x3_block(padding=1, **kwargs):

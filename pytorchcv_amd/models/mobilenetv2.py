@@ -8,7 +8,7 @@ __all__ = ['MobileNetV2', 'mobilenetv2_w1', 'mobilenetv2_w3d4', 'mobilenetv2_wd2
 
 import torch.nn as nn
 from .common.activ import lambda_relu6
-from .common.conv import conv1x1, conv1x1_block, conv3x3_block, dwconv3x3_block
+from .common.conv import conv1x1, conv1x1_block, conv3x3_block, dwconv3x3_block, mbconv_chain
 from ._tail import AvgPool2dNHWC, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
 
@@ -26,8 +26,12 @@ class LinearBottleneck(nn.Module):
         self.conv3 = conv1x1_block(in_channels=mid_channels, out_channels=out_channels, activation=None)
 
     def _run(self, a):
+        residual = a if self.residual else None
+        y = mbconv_chain(self.conv1 if self.use_exp_conv else None, self.conv2, self.conv3, a, residual=residual)
+        if y is not None:
+            return y                                     # the whole unit was one launch (csrc/mbconv.hpp)
         y = self.conv1(a) if self.use_exp_conv else a
-        return self.conv3(self.conv2(y), residual=(a if self.residual else None))
+        return self.conv3(self.conv2(y), residual=residual)
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)

@@ -11,7 +11,7 @@ __all__ = ['MobileNetV3', 'mobilenetv3_small_w7d20', 'mobilenetv3_small_wd2', 'm
 
 import torch.nn as nn
 from .common.activ import lambda_relu, lambda_hswish, lambda_hsigmoid, HSwish
-from .common.conv import conv1x1, conv1x1_block, conv3x3_block, dwconv3x3_block, dwconv5x5_block
+from .common.conv import conv1x1, conv1x1_block, conv3x3_block, dwconv3x3_block, dwconv5x5_block, mbconv_chain
 from .common.att import SEBlock, round_channels
 from ._tail import AvgPool2dNHWC, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
@@ -35,6 +35,11 @@ class MobileNetV3Unit(nn.Module):
         self.conv2 = conv1x1_block(in_channels=mid_channels, out_channels=out_channels, activation=None)
 
     def _run(self, a):
+        if not self.use_se:
+            y = mbconv_chain(self.exp_conv if self.use_exp_conv else None, self.conv1, self.conv2, a,
+                             residual=(a if self.residual else None))
+            if y is not None:
+                return y                                 # the whole unit was one launch (csrc/mbconv.hpp)
         y = self.exp_conv(a) if self.use_exp_conv else a
         y = self.conv1(y)
         if self.use_se:

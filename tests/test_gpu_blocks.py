@@ -199,3 +199,54 @@ def test_conv1x1_pair_unsupported_shapes_fall_back(cuda_device):
     x = engine.NHWC(torch.zeros((1, 4, 4, 128), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 128)
     r = engine.NHWC(torch.zeros((1, 4, 4, 512), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 512)
     assert conv_block_pair(first, x, r, nn.ReLU(), second) is None
+
+
+_MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
+    (2, 28, 28, 24, True, 24, 1, "relu6"), (2, 56, 56, 16, True, 24, 2, "relu6"), (2, 30, 27, 32, False, 16, 1, "relu6"),
+    (1, 28, 28, 96, True, 32, 1, "relu6"), (3, 59, 53, 24, True, 32, 2, "hswish"), (1, 112, 112, 32, False, 16, 1, "relu"),
+    (2, 33, 47, 40, True, 24, 1, "relu"), (2, 56, 56, 64, True, 32, 2, "relu6"),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
+def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, cuda_device):
+    """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
+    launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
+    from pytorchcv_amd.models.common.conv import mbconv_chain
+    from pytorchcv_amd.models.common.activ import create_activation_layer
+    from oracle import refnet
+    N, H, W, Cin, expand, Cout, stride, act = shape
+    unit = LinearBottleneck(in_channels=Cin, out_channels=Cout, stride=stride, expansion=expand, remove_exp_conv=True,
+                            activation=(lambda: create_activation_layer(act))).eval()
+    sd = util.synth_state_dict(unit.state_dict(), seed=31)
+    unit.load_state_dict(sd)
+    unit = pytorchcv_amd.set_compute_dtype(unit.to(cuda_device), dtype)
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    x = util.synth_input(N, Cin, H, W, seed=8)
+    xq = x.to(tdt)
+    a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
+    residual = a if unit.residual else None
+    with torch.no_grad():
+        fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
+        assert fused is not None, "this shape must be covered by the fused kernel"
+        y = unit.conv1(a) if unit.use_exp_conv else a
+        sep = unit.conv3(unit.conv2(y), residual=residual)
+    torch.cuda.synchronize()
+    f, s = fused.t.float().cpu(), sep.t.float().cpu()
+    assert f.shape == s.shape
+    ulp = 2.0 ** -7 if dtype == "bf16" else 2.0 ** -10
+    scale = max(1.0, float(s.abs().max()))
+    assert float((f - s).abs().max()) <= 2 * ulp * scale
+    # oracle, same rounding points
+    q = refnet.Quant(dtype)
+    sdc = {k: v.float() for k, v in sd.items()}
+    xr = q.r(x)
+    t = refnet.conv_block(sdc, "conv1.", xr, act=act, q=q) if expand else xr
+    t = refnet.conv_block(sdc, "conv2.", t, stride=stride, padding=1, groups=t.shape[1], act=act, q=q)
+    ref = refnet.conv_block(sdc, "conv3.", t, act=None, q=q, residual=(xr if unit.residual else None))
+    err = float((f.permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= 1e-2 * max(1.0, float(ref.abs().max())), err
