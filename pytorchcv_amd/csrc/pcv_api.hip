@@ -386,10 +386,15 @@ static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
     if (dt == PCV_BF16) return nrowt <= 2 ? mbconv_for<PCV_BF16, 2>(stride, expand) : mbconv_for<PCV_BF16, 6>(stride, expand);
     return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
 }
-static const int kMbMaxLds = 96 * 1024;
-static int mbconv_lds(int stride, int ka_x) {       // ka_x: K-steps of the resident x tile (0 without an expand convolution)
-    const int npt = stride == 1 ? 12 : 19, outpx = stride == 1 ? 128 : 64;
-    return (ka_x > 0 ? 1 : 2) * npt * 16 * 64 + outpx * 64 + ((npt * 16 + 15) & ~15) + ka_x * npt * 16 * 64;
+static const int kMbMaxLds = 150 * 1024;
+// LDS plan of one unit: prefetch the next tile's x (two buffers) when that still leaves room for two blocks per CU
+static MbLds mbconv_plan(int stride, bool expand, int ka, int nChunks, int nRowT, int* nbufX) {
+    MbLds two = mb_lds_layout(stride, expand, ka, nChunks, nRowT, 2);
+    if (!expand || two.total <= 80 * 1024) { *nbufX = 2; return two; }
+    MbLds one = mb_lds_layout(stride, expand, ka, nChunks, nRowT, 1);
+    if (one.total <= 80 * 1024 || two.total > kMbMaxLds) { *nbufX = 1; return one; }
+    *nbufX = 2;
+    return two;
 }
 static int enable_mbconv(pcv_ctx* ctx) {
     for (int dt = PCV_BF16; dt <= PCV_F16; ++dt)
@@ -430,7 +435,9 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
         ka = (de->Cin + 31) / 32;
         if (ka > 3) return "expand stage input wider than 96 channels";
     }
-    if (mbconv_lds(dd.stride_h, ka) > kMbMaxLds) return "input tile does not fit the LDS budget";
+    int nbuf = 0;
+    if (mbconv_plan(dd.stride_h, de != nullptr, ka, (Cmid + 31) / 32, (dp.Cout + 31) / 32 * 2, &nbuf).total > kMbMaxLds)
+        return "weights + tiles do not fit the LDS budget";
     const long cin = de ? de->Cin : Cmid;
     if ((long)dd.N * dd.H * dd.W * cin * 2 >= (1L << 31) || (long)dd.N * Ho * Wo * dp.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
     return nullptr;
@@ -1112,8 +1119,13 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     p.act_e = d_exp ? d_exp->act : 0; p.act_d = d_dw->act; p.act_p = d_proj->act; p.post = d_proj->post_act;
     if (p.nRowT > 6 || (d_exp && p.Kpad1 < 32 * p.ka) || p.Kpad2 < 32 * p.nChunks)
         return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
-    const int lds = mbconv_lds(S, p.ka);
-    hipLaunchKernelGGL(pick_mbconv(d_dw->dtype, S, d_exp != nullptr, p.nRowT), dim3((unsigned)p.nTiles), dim3(256), lds, (hipStream_t)stream, p);
+    const MbLds lds = mbconv_plan(S, d_exp != nullptr, p.ka, p.nChunks, p.nRowT, &p.nbufX);
+    mbconv_fn fn = pick_mbconv(d_dw->dtype, S, d_exp != nullptr, p.nRowT);
+    int nb = 0;
+    HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), 256, lds.total));
+    if (nb < 1) nb = 1;
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * nb);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds.total, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }
