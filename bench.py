@@ -235,10 +235,15 @@ def main():
     # per-launch HIP-event timing of the roofline kernel class (separate pass, not part of `value`)
     roof = None
     if rank == 0:
+        from pytorchcv_amd import engine as _engine
+        fuse_was = _engine.FUSE_UNITS
+        if klass == "depthwise":
+            _engine.FUSE_UNITS = False               # time the depthwise KERNEL on every layer (the fused units bypass it)
         with LaunchTimer(klass) as lt:
             for _ in range(max(3, min(args.steps, 10))):
                 with torch.no_grad():
                     net(x)                           # eager: events bracket every launch of the class
+        _engine.FUSE_UNITS = fuse_was
         s = lt.summary()
         if s is not None:
             if bound == "mfma":

@@ -247,7 +247,7 @@ class ConvRunner(object):
     def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
         """This convolution (+ residual, + post_act) and the 1x1 convolution `nxt` that consumes its output, as ONE launch
         (pcv_conv1x1_pair_fused): returns (y1, y2), or None when the pair of shapes is not covered by the fused kernel."""
-        if residual is None or self.depthwise or nxt.depthwise or self.pad4 is not None or nxt.pad4 is not None:
+        if not FUSE_UNITS or residual is None or self.depthwise or nxt.depthwise or self.pad4 is not None or nxt.pad4 is not None:
             return None
         if (self.bn is not None and self.bn.training) or (nxt.bn is not None and nxt.bn.training):
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
@@ -323,11 +323,16 @@ def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
     return NHWC(y, x.N, Ho, Wo, x.C)
 
 
+# Unit-level fusions (pcv_mbconv_fused, pcv_conv1x1_pair_fused) can be switched off to time the per-layer kernels on their own
+# (bench.py's roofline pass over the depthwise kernel class does that); the results are the same either way.
+FUSE_UNITS = os.environ.get("PCV_AMD_FUSE_UNITS", "1") != "0"
+
+
 def mbconv_fused(exp, exp_act: int, dw, dw_act: int, proj, proj_act: int, x: NHWC, residual, post_act: int):
     """[expand 1x1 ->] depthwise 3x3 -> project 1x1 (+ residual) as ONE launch (pcv_mbconv_fused); `exp`, `dw`, `proj` are
     the ConvRunners of the three blocks (`exp` may be None). Returns the unit output, or None when the triple of shapes is
     not covered by the fused kernel (the caller then issues the separate launches)."""
-    if not x.dense or not dw.depthwise or proj.depthwise or (exp is not None and exp.depthwise):
+    if not FUSE_UNITS or not x.dense or not dw.depthwise or proj.depthwise or (exp is not None and exp.depthwise):
         return None
     if any(r is not None and r.pad4 is not None for r in (exp, dw, proj)):
         return None
