@@ -69,6 +69,9 @@ typedef struct pcv_conv_desc {
     int32_t out_dtype;             /* pcv_dtype of y: dtype, or PCV_F32 (classifier logits) */
     int32_t x_cpitch;              /* channel pitch of x in elements: Cin, or 4 / round-up-8 for a padded stem input */
     int32_t x_wpitch;              /* row pitch of x in pixels: W, or W rounded up to even for a padded stem input */
+    int32_t y_cpitch;              /* channel pitch of y in elements: 0 or Cout = dense; wider when `y` points at a channel
+                                      slice of a concatenation buffer (torch.cat((identity, x), dim=1), densenet.py:58) -
+                                      honoured by pcv_conv2d_fused only, every other entry point requires a dense y */
 } pcv_conv_desc;
 
 /* ---- context ------------------------------------------------------------------------------------------ */
@@ -159,9 +162,11 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
 
 /* y[rows,C] = act(x * scale[c] + shift[c]): the BatchNorm2d + activation a PreConvBlock applies BEFORE its convolution
  * (conv.py:776-779) and PreResActivation (preresnet.py:199-222), for the places where it cannot ride in the producing
- * convolution's epilogue (the unit input, which the skip path needs un-activated). rows = N*H*W. */
+ * convolution's epilogue (the unit input, which the skip path needs un-activated). rows = N*H*W; x_cpitch (0 = C) is the
+ * channel pitch of x when its C channels are the leading slice of a wider concatenation buffer (densenet.py:55-59);
+ * y is dense. */
 int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C,
-               int act, int dtype, void* stream);
+               int x_cpitch, int act, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

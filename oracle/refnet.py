@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -464,6 +464,41 @@ def preresnet_forward(sd, x, blocks=18, bottleneck=None, conv1_stride=True, q=No
     return _classifier(sd, x, q)
 
 
+def dense_unit(sd, p, x, q=None):
+    """DenseUnit.forward (densenet.py:51-59): BN-ReLU-1x1, BN-ReLU-3x3, torch.cat((identity, x), dim=1)."""
+    q = q or Quant(None)
+    pre = bn_act(sd, p + "conv1.bn.", x, q)
+    y = pre_conv_chain(sd, [p + "conv1.", p + "conv2."], [1, 1], pre, q)
+    return torch.cat((x, y), dim=1)
+
+
+def dense_transition(sd, p, x, q=None):
+    """TransitionBlock.forward (densenet.py:87-91): pre-activated 1x1 convolution, AvgPool2d(2, 2)."""
+    q = q or Quant(None)
+    y = pre_conv_chain(sd, [p + "conv."], [1], bn_act(sd, p + "conv.bn.", x, q), q)
+    return q.r(F.avg_pool2d(y, kernel_size=2, stride=2))
+
+
+def densenet_forward(sd, x, q=None, taps=None):
+    """DenseNet.forward (densenet.py:156-160); stages/units are read from the state_dict (get_densenet, :204-235)."""
+    q = q or Quant(None)
+    x = preres_init_block(sd, "features.init_block.", q.r(x), q)
+    _tap(taps, "init_block", x)
+    i = 0
+    while ("features.stage{}.unit1.conv1.conv.weight".format(i + 1)) in sd:
+        sp = "features.stage{}.".format(i + 1)
+        if (sp + "trans{}.conv.conv.weight".format(i + 1)) in sd:
+            x = dense_transition(sd, sp + "trans{}.".format(i + 1), x, q)
+        j = 0
+        while (sp + "unit{}.conv1.conv.weight".format(j + 1)) in sd:
+            x = dense_unit(sd, sp + "unit{}.".format(j + 1), x, q)
+            j += 1
+        _tap(taps, "stage{}".format(i + 1), x)
+        i += 1
+    x = bn_act(sd, "features.post_activ.bn.", x, q)
+    return _classifier(sd, x, q)
+
+
 def tf_same_pad(h, w, kernel_size, stride=1, dilation=1):
     """calc_tf_padding, efficientnet.py:27-55. Returned in F.pad order: the reference hands (pad_h//2, pad_h - pad_h//2,
     pad_w//2, pad_w - pad_w//2) to F.pad, which reads it as (left, right, top, bottom)."""
@@ -565,6 +600,8 @@ for _n, _kw in {"preresnet10": dict(blocks=10), "preresnet12": dict(blocks=12), 
     MODEL_ARCH[_n] = ("preresnet", _kw)
     if _n != "preresnet269b":
         MODEL_ARCH["se" + _n] = ("preresnet", _kw)          # SE-PreResNet: same trunk, `se.` blocks in the state_dict
+for _n in ("densenet121", "densenet161", "densenet169", "densenet201"):
+    MODEL_ARCH[_n] = ("densenet", dict())
 for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
     MODEL_ARCH["efficientnet_" + _v] = ("efficientnet", dict(version=_v))
     for _t in ("b", "c"):
@@ -574,7 +611,7 @@ for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
            "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
            "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward,
-           "preresnet": preresnet_forward}
+           "preresnet": preresnet_forward, "densenet": densenet_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

@@ -28,7 +28,8 @@ class ConvDesc(ctypes.Structure):
     """Mirror of `pcv_conv_desc` (include/pcv_amd.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "N", "H", "W", "Cin", "Cout", "kh", "kw", "stride_h", "stride_w", "pad_t", "pad_l", "pad_b", "pad_r",
-        "dil_h", "dil_w", "groups", "act", "post_act", "has_residual", "dtype", "out_dtype", "x_cpitch", "x_wpitch")]
+        "dil_h", "dil_w", "groups", "act", "post_act", "has_residual", "dtype", "out_dtype", "x_cpitch", "x_wpitch",
+        "y_cpitch")]
 
 
 _SIGS = {
@@ -58,7 +59,7 @@ _SIGS = {
     "pcv_mbconv_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "pcv_mbconv_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP,
                               _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "pcv_bn_act": (_I, [_VP, _VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _VP]),
+    "pcv_bn_act": (_I, [_VP, _VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _VP]),
     "pcv_se_scale": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
 }
 

@@ -337,13 +337,13 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
 template <int DT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, void* __restrict__ y, long total8,
-                                                    int C, int act_code) {
+                                                    int C, int xpitch, int act_code) {
     const int C8 = C / 8;
     const ActClamp act = make_act(act_code);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         float v[8], a[8], b[8];
-        load8<DT>(x, (size_t)i * 8, v);
+        load8<DT>(x, (size_t)(i / C8) * xpitch + c0, v);          // x may be the leading channels of a wider (concat) tensor
         load8<PCV_F32>(scale, c0, a);
         load8<PCV_F32>(shift, c0, b);
 #pragma unroll

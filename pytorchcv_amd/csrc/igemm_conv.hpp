@@ -39,7 +39,8 @@ struct IgemmParams {
     uint32_t y_bytes;       // buffer num_records for y (16-bit non-ragged outputs are written with range-checked stores)
     int M;                  // N*Ho*Wo
     int Cout;               // valid output channels per group-block (== Cout_total when gridDim.y == 1)
-    int Cout_total;         // channel pitch of y / residual
+    int Cout_total;         // channel pitch of the residual (= all output channels)
+    int Ypitch;             // channel pitch of y: Cout_total, or wider when y is a channel slice of a concat buffer
     int cout_blk;           // output channels per blockIdx.y step
     int cin_blk;            // input-channel offset per blockIdx.y step
     int wrows_blk;          // packed weight rows per blockIdx.y step
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                 if constexpr (!FAST_STORE) {
                     if (m >= p.M) continue;
                 }
-                const size_t eoff = (size_t)m * p.Cout_total + chg;
+                const size_t eoff = (size_t)m * p.Cout_total + chg;          // residual element
+                const size_t yoff = (size_t)m * p.Ypitch + chg;              // output element
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -408,9 +410,9 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                 if constexpr (RAGGED) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (ch0 + e < p.Cout) store_elem<OT>(p.y, eoff + e, v[e]);
+                        if (ch0 + e < p.Cout) store_elem<OT>(p.y, yoff + e, v[e]);
                 } else if constexpr (OT == PCV_F32) {
-                    float* yp = reinterpret_cast<float*>(p.y) + eoff;
+                    float* yp = reinterpret_cast<float*>(p.y) + yoff;
                     *reinterpret_cast<f32x4*>(yp) = (f32x4){v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(yp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
                 } else {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                     // exactly one store instruction per (ip, j) for every wave: out-of-range pieces (tile tail, channel
                     // padding) get an offset beyond num_records and are dropped by the range check
                     const bool ok = ch0 < p.Cout && m < p.M;
-                    const uint32_t boff = ok ? (uint32_t)(eoff * 2) : 0x80000000u;
+                    const uint32_t boff = ok ? (uint32_t)(yoff * 2) : 0x80000000u;
                     __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
                 }
             }

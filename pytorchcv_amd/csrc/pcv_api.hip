@@ -365,7 +365,8 @@ static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc&
     auto plain1x1 = [](const pcv_conv_desc& d) {
         return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
                d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
-               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W);
+               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W) &&
+               (d.y_cpitch == 0 || d.y_cpitch == d.Cout);
     };
     if (!plain1x1(a) || !plain1x1(b)) return "both convolutions must be plain 1x1 stride 1";
     if (a.dtype != b.dtype || (a.dtype != PCV_BF16 && a.dtype != PCV_F16)) return "16-bit storage only";
@@ -410,7 +411,8 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
     auto plain1x1 = [](const pcv_conv_desc& d) {
         return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
                d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
-               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W);
+               (d.x_cpitch == 0 || d.x_cpitch == d.Cin) && (d.x_wpitch == 0 || d.x_wpitch == d.W) &&
+               (d.y_cpitch == 0 || d.y_cpitch == d.Cout);
     };
     if (dd.dtype != PCV_BF16 && dd.dtype != PCV_F16) return "16-bit storage only";
     if (dd.kh != 3 || dd.kw != 3 || dd.dil_h != 1 || dd.dil_w != 1 || dd.pad_t != 1 || dd.pad_l != 1 || dd.pad_b != 1 ||
@@ -641,6 +643,7 @@ static const char* check_dw(const pcv_conv_desc& d) {
     if (d.dil_h != 1 || d.dil_w != 1) return "depthwise: dilation unsupported";
     if (d.x_cpitch > 0 && d.x_cpitch != d.Cin) return "depthwise: padded channel pitch unsupported";
     if (d.x_wpitch > 0 && d.x_wpitch != d.W) return "depthwise: padded row pitch unsupported";
+    if (d.y_cpitch > 0 && d.y_cpitch != d.Cout) return "depthwise: y must be dense";
     return nullptr;
 }
 
@@ -703,6 +706,8 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
 
+    const bool sliced_y = d->y_cpitch > 0 && d->y_cpitch != d->Cout;
+    if (P.stem && sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
     if (P.stem) {
         StemParams q;
         q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;
@@ -729,7 +734,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         return PCV_OK;
     }
 
-    bool take_conv3 = P.conv3 && ctx->use_conv3;
+    bool take_conv3 = P.conv3 && ctx->use_conv3 && !sliced_y;
     if (take_conv3 && ctx->force_conv3_cfg < 0) {
         const int c3 = d->Cout <= 64 ? C3_64x512 : C3_128x256;
         const long long tiles = ((long long)((M64 + kConv3[c3].BP - 1) / kConv3[c3].BP)) * ((d->Cout + kConv3[c3].BM - 1) / kConv3[c3].BM);
@@ -800,8 +805,11 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     p.shift = shift;
     p.x_bytes = (uint32_t)xbytes;
     p.w_bytes = (uint32_t)P.w_bytes;
+    const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+    if (ypitch < d->Cout || (ypitch != d->Cout && (ypitch * esize(d->out_dtype)) % 16 != 0))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
     {
-        const unsigned long long ybytes = M64 * (unsigned long long)d->Cout * esize(d->out_dtype);
+        const unsigned long long ybytes = ((M64 - 1) * (unsigned long long)ypitch + d->Cout) * esize(d->out_dtype);
         if (ybytes >= 0x80000000ull && d->out_dtype != PCV_F32)
             return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
         p.y_bytes = ybytes >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ybytes;
@@ -809,6 +817,7 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     p.M = (int)M64;
     p.Cout = P.cout_blk;
     p.Cout_total = d->Cout;
+    p.Ypitch = ypitch;
     p.cout_blk = P.cout_blk;
     p.cin_blk = d->groups == 1 ? 0 : P.cin_blk;
     p.wrows_blk = P.wrows;
@@ -1130,20 +1139,22 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     return PCV_OK;
 }
 
-int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int act,
-               int dtype, void* stream) {
+int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int x_cpitch,
+               int act, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
-    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || C % 8 != 0 || !dtype_ok(dtype) || act < 0 || act > PCV_ACT_HSWISH)
-        return fail(ctx, PCV_ERR_INVALID, "pcv_bn_act: bad argument (C must be a multiple of 8)");
+    if (x_cpitch <= 0) x_cpitch = C;
+    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || C % 8 != 0 || x_cpitch < C || x_cpitch % 8 != 0 || !dtype_ok(dtype) ||
+        act < 0 || act > PCV_ACT_HSWISH)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_bn_act: bad argument (C and x_cpitch must be multiples of 8, x_cpitch >= C)");
     const long total8 = rows * (C / 8);
     long blocks = (total8 + 255) / 256;
     const long cap = (long)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
-    else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
-    else bn_act_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, act);
+    if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
+    else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
+    else bn_act_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

@@ -233,7 +233,7 @@ class ConvRunner(object):
         torch.cuda.current_stream(dev).synchronize()      # w32 & friends are temporaries; load-time only
         self.packed, self.scale, self.shift, self._key = packed, scale, shift, key
 
-    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None) -> NHWC:
+    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None, out=None) -> NHWC:
         """`pad4`: explicit (left, right, top, bottom) zero padding for this call (the `F.pad` a unit applies in front of
         a padding-0 convolution, efficientnet.py:108-109,189-190,236-237); it stays inside the kernel's bounds checks."""
         if pad4 is not None:
@@ -242,7 +242,7 @@ class ConvRunner(object):
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
         d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None)
         self.prepare(x, d)
-        return self._launch(x, d, residual)
+        return self._launch(x, d, residual, out)
 
     def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
         """This convolution (+ residual, + post_act) and the 1x1 convolution `nxt` that consumes its output, as ONE launch
@@ -269,7 +269,9 @@ class ConvRunner(object):
                                             _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
         return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels)
 
-    def _launch(self, x: NHWC, d: ConvDesc, residual):
+    def _launch(self, x: NHWC, d: ConvDesc, residual, out=None):
+        """`out` = (tensor [N, Ho, Wo, Ctot], channel offset): write the result into that channel slice of a wider
+        (concatenation) buffer instead of a fresh tensor - `torch.cat((identity, x), dim=1)` without the copy."""
         c = self.conv
         kh, kw = d.kh, d.kw
         Ho = (x.H + d.pad_t + d.pad_b - d.dil_h * (kh - 1) - 1) // d.stride_h + 1
@@ -277,12 +279,21 @@ class ConvRunner(object):
         if Ho <= 0 or Wo <= 0:
             raise RuntimeError("convolution output would be empty")
         out_dt = torch.float32 if d.out_dtype == 0 else x.dtype
-        y = torch.empty((x.N, Ho, Wo, c.out_channels), dtype=out_dt, device=x.device)
+        if out is not None:
+            buf, coff = out
+            if self.depthwise or tuple(buf.shape[:3]) != (x.N, Ho, Wo) or buf.dtype != out_dt or not buf.is_contiguous() or \
+                    coff % 8 != 0 or coff + c.out_channels > buf.shape[3] or buf.device != x.device:
+                raise RuntimeError("bad concatenation slice for a convolution output")
+            d.y_cpitch = int(buf.shape[3])
+            y = buf[:, :, :, coff:]                 # a view: its data_ptr is the first element of the slice
+        else:
+            y = torch.empty((x.N, Ho, Wo, c.out_channels), dtype=out_dt, device=x.device)
         if residual is not None:
-            if not residual.dense or residual.t.shape != y.shape or residual.dtype != x.dtype:
-                raise RuntimeError("residual shape/dtype mismatch: {} vs {}".format(tuple(residual.t.shape), tuple(y.shape)))
+            if not residual.dense or tuple(residual.t.shape) != (x.N, Ho, Wo, c.out_channels) or residual.dtype != x.dtype:
+                raise RuntimeError("residual shape/dtype mismatch: {} vs {}".format(
+                    tuple(residual.t.shape), (x.N, Ho, Wo, c.out_channels)))
         self._launch_range(x, d, residual, y, 0, x.N)
-        return NHWC(y, x.N, Ho, Wo, c.out_channels)
+        return None if out is not None else NHWC(y, x.N, Ho, Wo, c.out_channels)
 
     def _launch_range(self, x, d, residual, y, n0, n1):
         """Launch images [n0, n1); halve the range when one launch would exceed the 2 GiB addressing window."""
@@ -415,15 +426,15 @@ class BnActRunner(object):
     def run(self, x: NHWC, act: int) -> NHWC:
         if self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
-        if not x.dense:
-            raise RuntimeError("BatchNorm + activation on a padded handle")
+        if x.wpitch != x.W:
+            raise RuntimeError("BatchNorm + activation on a row-padded handle")
         if x.C != self.bn.num_features:
             raise RuntimeError("BatchNorm2d expects {} channels, got {}".format(self.bn.num_features, x.C))
         self.prepare(x)
-        y = torch.empty_like(x.t)
+        y = torch.empty((x.N, x.H, x.W, x.C), dtype=x.dtype, device=x.device)
         ctx = _ctx(x.device)
         _lib.check(_lib.lib().pcv_bn_act(ctx, _ptr(x.t), _ptr(self.scale), _ptr(self.shift), _ptr(y), x.N * x.H * x.W, x.C,
-                                         act, _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
+                                         x.cpitch, act, _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
         return NHWC(y, x.N, x.H, x.W, x.C)
 
 

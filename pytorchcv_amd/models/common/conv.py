@@ -203,7 +203,7 @@ class PreConvBlock(nn.Module):
             self._pcv_pre = engine.BnActRunner(self.bn)
         return self._pcv_pre.run(a, self.act_code())
 
-    def conv_then(self, a, next_block=None, residual=None):
+    def conv_then(self, a, next_block=None, residual=None, out=None):
         """This block's convolution applied to the already pre-activated `a`; `next_block`'s BN + activation (the
         pre-activation of the following PreConvBlock) ride in the epilogue, or `residual` is added (last block of a unit)."""
         key = id(next_block)
@@ -211,7 +211,7 @@ class PreConvBlock(nn.Module):
             bn = next_block.bn if (next_block is not None and next_block.normalize) else None
             self._pcv_runners[key] = engine.ConvRunner(self.conv, bn)
         act = next_block.act_code() if next_block is not None else 0
-        return self._pcv_runners[key].run(a, act=act, residual=residual)
+        return self._pcv_runners[key].run(a, act=act, residual=residual, out=out)
 
     def _run(self, a):
         pre = self.preact(a) if (self.normalize or self.activate) else a

@@ -56,6 +56,7 @@ def build_block(case):
     from pytorchcv_amd.models.common.activ import lambda_swish
     from pytorchcv_amd.models.common.norm import lambda_batchnorm2d
     from pytorchcv_amd.models.preresnet import PreResUnit, PreResInitBlock, PreResActivation
+    from pytorchcv_amd.models.densenet import DenseUnit, TransitionBlock
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
@@ -68,7 +69,8 @@ def build_block(case):
             "ResNeXtUnit": ResNeXtUnit, "SEResUnit": SEResUnit, "MobileNetV3Unit": MobileNetV3Unit,
             "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit,
             "pre_conv3x3_block": C.pre_conv3x3_block, "pre_conv1x1_block": C.pre_conv1x1_block, "PreResUnit": PreResUnit,
-            "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation}[kind]
+            "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation, "DenseUnit": DenseUnit,
+            "TransitionBlock": TransitionBlock}[kind]
     return ctor(**kw).eval()
 
 
