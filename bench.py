@@ -70,9 +70,9 @@ class LaunchTimer(object):
         timer = self
         self._orig = engine.ConvRunner._launch
 
-        def timed(runner, x, d, residual):
-            if timer.classify(runner, d) != timer.klass:
-                return timer._orig(runner, x, d, residual)
+        def timed(runner, x, d, residual, out=None):
+            if out is not None or timer.classify(runner, d) != timer.klass:
+                return timer._orig(runner, x, d, residual, out)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             y = timer._orig(runner, x, d, residual)
