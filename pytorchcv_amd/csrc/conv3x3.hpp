@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv3x3_kernel(const Conv3Par
     using I2 = std::integral_constant<int, 2>;
 
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+    const bool late = (p.flags & 4) != 0 && (wave & 4) != 0;
     TileState cur, nxt;
     setup(tile, cur);
     col_masks(cur.p0);
@@ -229,16 +230,21 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void conv3x3_kernel(const Conv3Par
     while (true) {
         // ---- groups 0 .. G-2: the following group belongs to the same tile -----------------------------------------
         for (int g = 0; g + 1 < G; ++g) {
+            // Waves w and w + 4 share a SIMD. With `late` the upper half of the block issues its DMA AFTER the step's MFMAs,
+            // the lower half before: on every SIMD one wave is in its (issue-bound) DMA phase while the other feeds the MFMA
+            // pipe - what two independent 4-wave blocks do by drifting apart, and one 8-wave block in lockstep cannot.
             sync(std::integral_constant<int, WL>{});
-            issue_w(cur, g, 2);
-            issue_x(cur, g + 1, xb ^ 1);
+            if (!late) { issue_w(cur, g, 2); issue_x(cur, g + 1, xb ^ 1); }
             compute(I0{}, xb);
+            if (late) { issue_w(cur, g, 2); issue_x(cur, g + 1, xb ^ 1); }
             sync(std::integral_constant<int, WL + XL>{});
-            issue_w(cur, g + 1, 0);
+            if (!late) issue_w(cur, g + 1, 0);
             compute(I1{}, xb);
+            if (late) issue_w(cur, g + 1, 0);
             sync(std::integral_constant<int, WL + XL>{});
-            issue_w(cur, g + 1, 1);
+            if (!late) issue_w(cur, g + 1, 1);
             compute(I2{}, xb);
+            if (late) issue_w(cur, g + 1, 1);
             xb ^= 1;
         }
         // ---- last group: prefetch the next tile's first group, fetch the epilogue operands, finish the tile ----------
