@@ -26,6 +26,12 @@ __global__ __launch_bounds__(256, 2) void k(const s16x8* __restrict__ src, float
     s16x8 a[4], b[4];
     for (int i = 0; i < 4; ++i) { a[i] = lds[0][i * 64 + lane]; b[i] = lds[0][(4 + i) * 64 + lane]; }
     const int wave = tid >> 6;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 apre[8];
+    if (MODE & 16) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) apre[f] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)((f * 64 + lane) * 16), 0, 0);
+    }
     for (int it = 0; it < iters; ++it) {
         if (MODE & 2) __syncthreads();          // as in the conv kernels: barrier (waits for the DMA issued one step ago) ...
         if (MODE & 4) {                           // ... then the next stage's DMA, then this stage's MFMAs
@@ -34,12 +40,23 @@ __global__ __launch_bounds__(256, 2) void k(const s16x8* __restrict__ src, float
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dma_stage[it & 1] + (wave * NDMA + d) * 1024),
                                                          16, (uint32_t)(((it * 7 + d) & 31) * 1024 + lane * 16), 0, 0, 0);
         }
+        u32x4 acur[8];
+        if (MODE & 16) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acur[f] = apre[f];
+#pragma unroll
+            for (int f = 0; f < 8; ++f)          // next K-step's A fragments: 16 contiguous bytes per lane, L2-resident weights
+                apre[f] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (uint32_t)(((((it + 1) * 5 + f) & 15) * 64 + lane) * 16), 0, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (FROM_LDS) {
                 const s16x8* st = &lds[it & 1][ks * 8 * 64];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a[i] = st[i * 64 + lane]; b[i] = st[(4 + i) * 64 + lane]; }
+                for (int i = 0; i < 4; ++i) {
+                    if (MODE & 16) a[i] = __builtin_bit_cast(s16x8, acur[ks * 4 + i]); else a[i] = st[i * 64 + lane];
+                    b[i] = st[(4 + i) * 64 + lane];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -83,5 +100,7 @@ int main() {
     run("  + 8 LDS-DMA pieces per wave per 32 MFMA", k<5, 8>);
     run("  + barrier + 4 pieces", k<7, 4>);
     run("  + barrier + 8 pieces (generic 128x128 tile)", k<7, 8>);
+    run("A: 8 global loads -> regs; B: LDS + barrier + 4 pieces", k<23, 4>);
+    run("A: 8 global loads -> regs; B: LDS + barrier + 8 pieces", k<23, 8>);
     return 0;
 }
