@@ -91,6 +91,12 @@ int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H,
 /* x: NHWC [N,H,W,C] in dtype -> y: fp32 NCHW (block-level drop-in use; not on the whole-net hot path). */
 int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
 
+/* Decoded uint8 frames [N,Hs,Ws,C] (C <= 4) -> the network's input: crop [top, top+H) x [left, left+W), (u8/255 - mean[c]) *
+ * inv_std[c] (the "ordinary normalization" every pretrained model expects, README.md:12-13), NHWC [N,H,wpitch,4] in dtype with
+ * zero pad channels/columns - exactly what pcv_nchw_to_nhwc would produce from the fp32 NCHW tensor of the host pipeline. */
+int pcv_preprocess_u8(pcv_ctx* ctx, const unsigned char* x, void* y, int N, int Hs, int Ws, int C, int top, int left,
+                      int H, int W, int wpitch, const float* mean, const float* inv_std, int dtype, void* stream);
+
 /* ---- weights (load time) ------------------------------------------------------------------------------- */
 /* Size of the packed-weight blob of a dense or grouped conv (groups < Cin). */
 int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);

@@ -352,3 +352,35 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x,
         store8<DT>(y, (size_t)i * 8, v);
     }
 }
+
+// ---- ImageNet preprocessing: uint8 HWC image batch -> normalised network input in one pass --------------------------------
+// The reference's models expect "ordinary normalization" of a centre crop (README.md:12-13; model_metainfos.csv columns
+// img_size = 224, img_scale = 0.875): x = (u8 / 255 - mean[c]) / std[c]. What the stem kernel wants is NHWC with the channels
+// padded to 4 and the row pitch even, in the compute type; producing that directly from the decoded uint8 frames folds
+// crop + normalise + layout + cast into one read of 1 byte per element (instead of an fp32 NCHW tensor written by the host
+// pipeline and re-read by nchw_to_nhwc). One thread = one output pixel.
+template <int OT>
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ x, void* __restrict__ y, int N,
+                                                           int Hs, int Ws, int C, int top, int left, int H, int W, int cpitch,
+                                                           int wpitch, const float* __restrict__ mean,
+                                                           const float* __restrict__ inv_std) {
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;       // over N*H*wpitch
+    if (pix >= (long)N * H * wpitch) return;
+    const int w = (int)(pix % wpitch);
+    const long nh = pix / wpitch;
+    const int h = (int)(nh % H);
+    const int n = (int)(nh / H);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (w < W) {
+        const unsigned char* src = x + (((size_t)n * Hs + top + h) * Ws + left + w) * C;
+        for (int c = 0; c < C && c < 4; ++c) v[c] = ((float)src[c] * (1.f / 255.f) - mean[c]) * inv_std[c];
+    }
+    const size_t eoff = (size_t)pix * cpitch;
+    if constexpr (OT == PCV_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + eoff) = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+        u32x2 o = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(y) + eoff) = o;
+    }
+}
+

@@ -1079,6 +1079,23 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     return PCV_OK;
 }
 
+int pcv_preprocess_u8(pcv_ctx* ctx, const unsigned char* x, void* y, int N, int Hs, int Ws, int C, int top, int left, int H,
+                      int W, int wpitch, const float* mean, const float* inv_std, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !y || !mean || !inv_std || N <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0 || top < 0 ||
+        left < 0 || top + H > Hs || left + W > Ws || wpitch < W || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_preprocess_u8: bad argument (C <= 4, crop inside the frame, wpitch >= W)");
+    const long total = (long)N * H * wpitch;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) preprocess_u8_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
+    else if (dtype == PCV_F16) preprocess_u8_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
+    else preprocess_u8_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
 int pcv_mbconv_supported(const pcv_conv_desc* d_exp, const pcv_conv_desc* d_dw, const pcv_conv_desc* d_proj) {
     return (d_dw && d_proj && mbconv_unsupported(d_exp, *d_dw, *d_proj) == nullptr) ? 1 : 0;
 }
