@@ -10,6 +10,7 @@
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "conv3x3_inst.hpp"
+#include "hconv3x3_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "mbconv.hpp"
@@ -23,6 +24,7 @@ IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
 CONV3_INSTANCES(CONV3_DECLARE, PCV_BF16)
 CONV3_INSTANCES(CONV3_DECLARE, PCV_F16)
 CONV3_INSTANCES(CONV3_DECLARE, PCV_F32)
+HCONV_INSTANCES(HCONV_DECLARE)
 
 struct pcv_ctx {
     int device = 0;
@@ -35,6 +37,7 @@ struct pcv_ctx {
     int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int use_hconv = 0;          // halo-reuse 3x3 kernel (hconv3x3.hpp) for the eligible 3x3/s1/p1 layers
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
@@ -329,6 +332,27 @@ static int enable_conv3(pcv_ctx* ctx) {
     return PCV_OK;
 }
 
+// ---- halo-reuse 3x3 kernel (hconv3x3.hpp) -----------------------------------------------------------------------------------
+typedef void (*hconv_fn)(const HConvParams);
+struct HConvInfo { int BM, BP, threads, lds; };
+static const HConvInfo kHConv[2] = {
+    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 128) * 128},
+    {64, 256, 256, 3 * 64 * 128 + 2 * (256 + 128) * 128},
+};
+template <int DT> static hconv_fn hconv_for(int cfg) { return cfg == 0 ? hconv3x3_kernel<DT, 2, 4> : hconv3x3_kernel<DT, 1, 4>; }
+static hconv_fn pick_hconv(int dt, int cfg) {
+    if (dt == PCV_BF16) return hconv_for<PCV_BF16>(cfg);
+    if (dt == PCV_F16) return hconv_for<PCV_F16>(cfg);
+    return hconv_for<PCV_F32>(cfg);
+}
+static int enable_hconv(pcv_ctx* ctx) {
+    for (int dt = 0; dt < 3; ++dt)
+        for (int cfg = 0; cfg < 2; ++cfg)
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_hconv(dt, cfg)),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kHConv[cfg].lds));
+    return PCV_OK;
+}
+
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
 static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16;
 static int g_stem_blocks_per_cu[2];
@@ -501,10 +525,12 @@ int pcv_create(pcv_ctx** out, int device) {
     if (const char* e = std::getenv("PCV_AMD_PERSIST")) ctx->persist_mode = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_CONV3")) ctx->use_conv3 = std::atoi(e);
+    if (const char* e = std::getenv("PCV_AMD_HCONV")) ctx->use_hconv = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_CONV3_CFG")) ctx->force_conv3_cfg = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_C3FLAGS")) ctx->conv3_flags = std::atoi(e);
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_conv3(ctx);
+    if (rc == PCV_OK) rc = enable_hconv(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc == PCV_OK) rc = enable_mbconv(ctx);
@@ -531,6 +557,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "c3flags") ctx->conv3_flags = value;
     else if (k == "tile") ctx->force_tile = value;
     else if (k == "pair_pb") ctx->pair_pb = value;
+    else if (k == "hconv") ctx->use_hconv = value;
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
@@ -734,6 +761,32 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         return PCV_OK;
     }
 
+    if (P.conv3 && ctx->use_hconv && !sliced_y && d->W <= 63 && d->Cout % 8 == 0 && d->out_dtype == d->dtype &&
+        (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * (unsigned long long)d->Cout * P.ES < 0x80000000ull) {
+        HConvParams q;
+        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
+        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
+        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * P.ES);
+        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.Cout = d->Cout;
+        q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.CS = d->Cin / (8 * P.CE);
+        q.Kpad = P.Kpad;
+        q.act = d->act; q.post_act = d->post_act;
+        const int cfg = d->Cout <= 64 ? 1 : 0;
+        const HConvInfo& T = kHConv[cfg];
+        q.nChTiles = (d->Cout + T.BM - 1) / T.BM;
+        const long long nT = ((M64 + T.BP - 1) / T.BP) * q.nChTiles;
+        q.nTiles = (int)nT;
+        long long nb = (long long)ctx->num_cu;                        // one block per CU (120-144 KB of LDS)
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        hipLaunchKernelGGL(pick_hconv(d->dtype, cfg), dim3((unsigned)nb), dim3(T.threads), T.lds, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
     bool take_conv3 = P.conv3 && ctx->use_conv3 && !sliced_y;
     if (take_conv3 && ctx->force_conv3_cfg < 0) {
         const int c3 = d->Cout <= 64 ? C3_64x512 : C3_128x256;

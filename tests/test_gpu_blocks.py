@@ -118,10 +118,12 @@ _CONV3_SHAPES = [
     (5, 512, 512, 7, 7, False),      # images smaller than a tile: many image borders inside one tile
     (1, 64, 192, 10, 14, False),     # H != W, Cout not a multiple of the 128-channel tile
     (40, 128, 64, 9, 5, True),       # tiny odd maps, several tiles, 64-channel config with residual
+    (1, 64, 64, 5, 63, True),        # widest map the halo kernel stages (W + 1 = 64)
+    (1, 64, 128, 3, 70, False),      # wider than that: the halo kernel must hand over to the generic path
 ]
 
 
-@pytest.mark.parametrize("use_conv3", [False, True], ids=["generic", "conv3x3_kernel"])
+@pytest.mark.parametrize("use_conv3", [False, True, "hconv"], ids=["generic", "conv3x3_kernel", "hconv3x3_kernel"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
 def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
@@ -136,7 +138,9 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
     from pytorchcv_amd import _lib
     ctx = _lib.ctx_for(0)
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 1 if use_conv3 else 0), ctx)
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 1 if use_conv3 is True else 0), ctx)
+    hconv_default = 0                                             # restored below (the product default: off)
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"hconv", 1 if use_conv3 == "hconv" else 0), ctx)
     x = util.synth_input(N, C, H, W, seed=21)
     res = util.synth_input(N, Cout, H, W, seed=22) if use_res else None
     with torch.no_grad():
@@ -148,6 +152,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
                             post_act="relu" if use_res else None)
     d = (y - ref).abs()
     _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 0), ctx)
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"hconv", hconv_default), ctx)
     if dtype == "fp32":
         assert float(d.max()) <= 1e-3
     else:

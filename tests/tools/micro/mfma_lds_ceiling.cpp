@@ -11,14 +11,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // MODE bit 0: operands re-read from LDS; bit 1: one __syncthreads per 32 MFMAs (the K-step barrier of the conv kernels);
 // bit 2: NDMA LDS-DMA pieces (1 KB each, L2-resident source) issued per 32 MFMAs into a third LDS stage nobody reads.
-template <int MODE, int NDMA>
-__global__ __launch_bounds__(256, 2) void k(const s16x8* __restrict__ src, float* __restrict__ out, int iters) {
+template <int MODE, int NDMA, int TPB = 256>
+__global__ __launch_bounds__(TPB, 512 / TPB) void k(const s16x8* __restrict__ src, float* __restrict__ out, int iters) {
     constexpr bool FROM_LDS = (MODE & 1) != 0;
-    __shared__ __attribute__((aligned(16))) char dma_stage[2][NDMA > 0 ? NDMA * 4 * 1024 : 16];
+    __shared__ __attribute__((aligned(16))) char dma_stage[2][NDMA > 0 ? NDMA * (TPB / 64) * 1024 : 16];
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16x8*>(src), 0, 2 * 8 * 64 * 2 * 16, 0x00020000);
     __shared__ __attribute__((aligned(16))) s16x8 lds[2][8 * 64 * 2];      // 2 stages x (8 fragments x 64 lanes) x 2 K-steps
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 2 * 8 * 64 * 2; i += 256) (&lds[0][0])[i] = src[i];
+    for (int i = tid; i < 2 * 8 * 64 * 2; i += TPB) (&lds[0][0])[i] = src[i];
     __syncthreads();
     f32x4 acc[4][4];
     for (int i = 0; i < 4; ++i)
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void k(const s16x8* __restrict__ src, float
     float s = 0.f;
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    out[blockIdx.x * 256 + tid] = s;
+    out[blockIdx.x * TPB + tid] = s;
 }
 
 int main() {
@@ -75,10 +75,22 @@ int main() {
     std::vector<short> h(n * 8);
     for (auto& v : h) v = (short)(0x3c00 + (rand() & 0x3ff) - ((rand() & 1) ? 0x8000 : 0));     // bf16 around +-1
     s16x8* src; float* out;
-    (void)hipMalloc(&src, n * 16); (void)hipMalloc(&out, 512 * 256 * 4);
+    (void)hipMalloc(&src, n * 16); (void)hipMalloc(&out, 512 * 512 * 4);
     (void)hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 10000;
+    auto run8 = [&](const char* name, void (*fn)(const s16x8*, float*, int)) {     // one 8-wave block per CU
+        float best = 1e9;
+        for (int rep = 0; rep < 4; ++rep) {
+            (void)hipEventRecord(e0);
+            fn<<<256, 512>>>(src, out, iters);
+            (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double flop = 256.0 * 8 * iters * 2 * 16 * (2.0 * 16 * 16 * 32);
+        printf("%-58s 8-wave block  : %6.1f ms  %5.0f TFLOP/s\n", name, best, flop / best / 1e9);
+    };
     auto run = [&](const char* name, void (*fn)(const s16x8*, float*, int)) {
         for (int blocks = 256; blocks <= 512; blocks *= 2) {
             float best = 1e9;
@@ -100,6 +112,9 @@ int main() {
     run("  + 8 LDS-DMA pieces per wave per 32 MFMA", k<5, 8>);
     run("  + barrier + 4 pieces", k<7, 4>);
     run("  + barrier + 8 pieces (generic 128x128 tile)", k<7, 8>);
+    run8("  + barrier + 2 pieces", k<7, 2, 512>);
+    run8("  + barrier + 4 pieces", k<7, 4, 512>);
+    run8("  + barrier + 8 pieces", k<7, 8, 512>);
     run("A: 8 global loads -> regs; B: LDS + barrier + 4 pieces", k<23, 4>);
     run("A: 8 global loads -> regs; B: LDS + barrier + 8 pieces", k<23, 8>);
     return 0;
