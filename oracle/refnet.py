@@ -569,6 +569,12 @@ MODEL_ARCH = {
     "resnet50b": ("resnet", dict(blocks=50, conv1_stride=False)),
     "resnet101": ("resnet", dict(blocks=101)),
     "resnet152": ("resnet", dict(blocks=152)),
+    "resnet10": ("resnet", dict(blocks=10)), "resnet12": ("resnet", dict(blocks=12)), "resnet14": ("resnet", dict(blocks=14)),
+    "resnet16": ("resnet", dict(blocks=16)), "resnet26": ("resnet", dict(blocks=26, bottleneck=False)),
+    "resnetbc14b": ("resnet", dict(blocks=14, bottleneck=True, conv1_stride=False)),
+    "resnetbc26b": ("resnet", dict(blocks=26, bottleneck=True, conv1_stride=False)),
+    "resnetbc38b": ("resnet", dict(blocks=38, bottleneck=True, conv1_stride=False)),
+    "resnet101b": ("resnet", dict(blocks=101, conv1_stride=False)), "resnet152b": ("resnet", dict(blocks=152, conv1_stride=False)),
     "mobilenetv2_w1": ("mobilenetv2", dict(width_scale=1.0)),
     "mobilenetv2_w3d4": ("mobilenetv2", dict(width_scale=0.75)),
     "mobilenetv2_wd2": ("mobilenetv2", dict(width_scale=0.5)),
@@ -583,6 +589,7 @@ MODEL_ARCH = {
     "seresnext101_32x4d": ("seresnext", dict(blocks=101, cardinality=32, bottleneck_width=4)),
     "mobilenet_w1": ("mobilenet", dict(width_scale=1.0)),
     "mobilenet_wd2": ("mobilenet", dict(width_scale=0.5)),
+    "mobilenet_w3d4": ("mobilenet", dict(width_scale=0.75)), "mobilenet_wd4": ("mobilenet", dict(width_scale=0.25)),
 }
 for _v in ("small", "large"):
     for _t in ("w7d20", "wd2", "w3d4", "w1", "w5d4"):

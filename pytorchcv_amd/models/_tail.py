@@ -3,7 +3,7 @@
     nn.AvgPool2d (same attribute names, no state), the classifier tail and the pretrained-weights hook of every factory.
 """
 
-__all__ = ['MaxPool2dNHWC', 'AvgPool2dNHWC', 'GlobalAvgPool2dNHWC', 'LinearHead', 'run_net', 'maybe_load_pretrained', 'init_conv_params']
+__all__ = ['MaxPool2dNHWC', 'AvgPool2dNHWC', 'GlobalAvgPool2dNHWC', 'LinearHead', 'run_net', 'check_channels', 'maybe_load_pretrained', 'init_conv_params']
 
 import os
 import torch
@@ -74,8 +74,29 @@ class _LinearAsConv(object):
         return self._lin.bias
 
 
+def check_channels(net: nn.Module):
+    """The MI355X kernels move activations in 16-byte NHWC chunks: every internal channel count must be a multiple of 8 (the
+    network input and the classifier output are exempt - padded stem, ragged epilogue; SE layers are fp32 FCs of any width).
+    A variant that breaks this (the narrow MobileNetV2 widths) still constructs and loads weights like the reference's, but
+    its forward is refused up front with the offending layer named, not somewhere inside the first launch."""
+    if getattr(net, "_pcv_channels_ok", False):
+        return
+    from .common.att import SEBlock
+    se_prefixes = tuple(n + "." for n, m in net.named_modules() if isinstance(m, SEBlock))
+    convs = [(n, m) for n, m in net.named_modules() if isinstance(m, nn.Conv2d) and not n.startswith(se_prefixes)]
+    for i, (n, m) in enumerate(convs):
+        cin_ok = m.in_channels % 8 == 0 or (i == 0 and m.in_channels <= 4)
+        cout_ok = m.out_channels % 8 == 0 or n.startswith("output")
+        if not (cin_ok and cout_ok):
+            raise NotImplementedError(
+                "{}: layer {} has {} -> {} channels; the MI355X path needs multiples of 8 (this width variant is not supported "
+                "yet)".format(type(net).__name__, n, m.in_channels, m.out_channels))
+    net._pcv_channels_ok = True
+
+
 def run_net(net: nn.Module, x, head):
     """Whole-net forward: NCHW fp32 in -> NHWC hot path -> fp32 logits [N, num_classes] out."""
+    check_channels(net)
     if isinstance(x, engine.NHWC):
         return head(net.features(x))
     if not torch.is_tensor(x) or x.dim() != 4:

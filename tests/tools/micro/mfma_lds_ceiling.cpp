@@ -15,7 +15,7 @@ template <int MODE, int NDMA, int TPB = 256>
 __global__ __launch_bounds__(TPB, 512 / TPB) void k(const s16x8* __restrict__ src, float* __restrict__ out, int iters) {
     constexpr bool FROM_LDS = (MODE & 1) != 0;
     __shared__ __attribute__((aligned(16))) char dma_stage[2][NDMA > 0 ? NDMA * (TPB / 64) * 1024 : 16];
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16x8*>(src), 0, 2 * 8 * 64 * 2 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<s16x8*>(src), 0, (MODE & 32) ? (4 << 20) : 2 * 8 * 64 * 2 * 16, 0x00020000);
     __shared__ __attribute__((aligned(16))) s16x8 lds[2][8 * 64 * 2];      // 2 stages x (8 fragments x 64 lanes) x 2 K-steps
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 2 * 8 * 64 * 2; i += TPB) (&lds[0][0])[i] = src[i];
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(TPB, 512 / TPB) void k(const s16x8* __restrict__ sr
 #pragma unroll
             for (int d = 0; d < NDMA; ++d)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dma_stage[it & 1] + (wave * NDMA + d) * 1024),
-                                                         16, (uint32_t)(((it * 7 + d) & 31) * 1024 + lane * 16), 0, 0, 0);
+                                                         16, (MODE & 32) ? (((uint32_t)(it * NDMA + d) * 40503u + blockIdx.x * 9973u + wave * 613u) & 4095u) * 1024u + lane * 16u
+                                                                         : (uint32_t)(((it * 7 + d) & 31) * 1024 + lane * 16), 0, 0, 0);
         }
         u32x4 acur[8];
         if (MODE & 16) {
@@ -75,7 +76,8 @@ int main() {
     std::vector<short> h(n * 8);
     for (auto& v : h) v = (short)(0x3c00 + (rand() & 0x3ff) - ((rand() & 1) ? 0x8000 : 0));     // bf16 around +-1
     s16x8* src; float* out;
-    (void)hipMalloc(&src, n * 16); (void)hipMalloc(&out, 512 * 512 * 4);
+    if (hipMalloc(&src, 4 << 20) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    (void)hipMemset(src, 0x3c, 4 << 20); (void)hipMalloc(&out, 512 * 512 * 4);
     (void)hipMemcpy(src, h.data(), n * 16, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int iters = 10000;
@@ -115,6 +117,9 @@ int main() {
     run8("  + barrier + 2 pieces", k<7, 2, 512>);
     run8("  + barrier + 4 pieces", k<7, 4, 512>);
     run8("  + barrier + 8 pieces", k<7, 8, 512>);
+    run("  + barrier + 4 pieces, source = 4 MB in L2 (not L1)", k<39, 4>);
+    run8("  + barrier + 4 pieces, source = 4 MB in L2 (not L1)", k<39, 4, 512>);
+    run8("  + barrier + 8 pieces, source = 4 MB in L2 (not L1)", k<39, 8, 512>);
     run("A: 8 global loads -> regs; B: LDS + barrier + 4 pieces", k<23, 4>);
     run("A: 8 global loads -> regs; B: LDS + barrier + 8 pieces", k<23, 8>);
     return 0;
