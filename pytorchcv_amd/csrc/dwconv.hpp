@@ -280,3 +280,142 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+// ---- depthwise 5x5 (dwconv5x5_block, conv.py:511-543: MobileNetV3, EfficientNet), row-streaming formulation -----------------------
+// The register-window scheme above needs KS*KS input chunks AND KS*KS weights live per thread: 200 registers at 5x5 even with 4
+// channels per thread, which spilled. Here a thread keeps only ONE input row of its 5 columns and accumulates it into the (up to)
+// five output rows it touches: input row t of the strip feeds output row o = (t - dy) / S through filter row dy. Live state: 25
+// weights + 5 (stride 1) or 3 (stride 2) accumulators + one row = ~170 registers, nothing spills, the same 5 loads per output row.
+// One thread = 4 channels (8 bytes at 16 bit) of one output column over its strip of rows, like dwconv_kernel<..., 4>.
+template <int DT, int S, bool FAST>
+__global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = 5, CPT = 4, NV = 2;
+    constexpr int ES = Elem<DT>::BYTES;
+    constexpr int NSLOT = S == 1 ? 5 : 3;          // output rows in flight
+    constexpr int PERIOD = S == 1 ? 5 : 6;         // input rows after which the (phase -> slot) pattern repeats
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.total) return;
+    const int c4 = (int)(idx % p.C8);
+    long t0 = idx / p.C8;
+    const int wo = (int)(t0 % p.Wo);
+    t0 /= p.Wo;
+    const int seg = (int)(t0 % p.nseg);
+    const int n = (int)(t0 / p.nseg);
+    const int c0 = c4 * CPT;
+    const int ho_begin = seg * p.TH;
+    const int nrows = min(p.Ho, ho_begin + p.TH) - ho_begin;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+
+    f32x2 wgt[KS * KS][NV];
+#pragma unroll
+    for (int k = 0; k < KS * KS; ++k) {
+        float w4[CPT];
+        loadn<DT, CPT>(p.w, (size_t)k * p.C + c0, w4);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) wgt[k][e] = (f32x2){w4[2 * e], w4[2 * e + 1]};
+    }
+    f32x2 sc[NV], sf[NV];
+    {
+        float a4[CPT], b4[CPT];
+        loadn<PCV_F32, CPT>(p.scale, c0, a4);
+        loadn<PCV_F32, CPT>(p.shift, c0, b4);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { sc[e] = (f32x2){a4[2 * e], a4[2 * e + 1]}; sf[e] = (f32x2){b4[2 * e], b4[2 * e + 1]}; }
+    }
+    const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+
+    const int wi0 = wo * S - p.pl;
+    uint32_t coloff[KS];
+#pragma unroll
+    for (int q = 0; q < KS; ++q)
+        coloff[q] = (unsigned)(wi0 + q) < (unsigned)p.W ? (uint32_t)(((wi0 + q) * p.C + c0) * ES) : 0x80000000u;
+    const uint32_t rowbytes = (uint32_t)(p.W * p.C * ES);
+    const uint32_t imgoff = (uint32_t)n * (uint32_t)p.H * rowbytes;
+    auto fetch_row = [&](int hi, bool need, RawChunk<DT, CPT> (&row)[KS]) {
+        const bool rowok = need && (unsigned)hi < (unsigned)p.H;
+        const uint32_t rbase = imgoff + (uint32_t)hi * rowbytes;
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+            raw_load<DT, CPT>(xrsrc, (rowok && coloff[q] != 0x80000000u) ? rbase + coloff[q] : 0x80000000u, row[q]);
+    };
+
+    f32x2 acc[NSLOT][NV];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) acc[s][e] = (f32x2){0.f, 0.f};
+
+    const int hi_first = ho_begin * S - p.pt;
+    const int nsteps = (nrows - 1) * S + KS;       // input rows this strip touches
+    // input rows live in a ring with one slot per phase of the unroll period: the row of step t sits in ring[t % PERIOD] and the
+    // row PD steps ahead is requested into its own (static) slot - no register copies, nothing waits on the newest loads
+    constexpr int PD = 2;
+    RawChunk<DT, CPT> ring[PERIOD][KS];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) fetch_row(hi_first + d, d < nsteps, ring[d]);
+    int t = 0;
+    while (t < nsteps) {
+        static_for<PERIOD>([&](auto PHC) {
+            constexpr int PH = decltype(PHC)::value;
+            if (t < nsteps) {
+                fetch_row(hi_first + t + PD, t + PD < nsteps, ring[(PH + PD) % PERIOD]);
+                f32x2 xv[KS][NV];
+#pragma unroll
+                for (int q = 0; q < KS; ++q) raw_to_f32x2<DT, CPT>(ring[PH][q], xv[q]);
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+                    const int d = PH - dy;                                 // S * (output row), modulo the unroll period
+                    if (S == 1 || (d & 1) == 0) {                          // stride 2: this input row only meets every other filter row
+                        const int slot = (((S == 1 ? d : d / 2) % NSLOT) + NSLOT) % NSLOT;
+                        if (t - dy >= 0) {
+#pragma unroll
+                            for (int q = 0; q < KS; ++q)
+#pragma unroll
+                                for (int e = 0; e < NV; ++e) pk_fma_acc(acc[slot][e], xv[q][e], wgt[dy * KS + q][e]);
+                        }
+                    }
+                }
+                // the output row whose last filter row (dy = 4) was this input row is complete
+                {
+                    const int d = PH - (KS - 1);
+                    if (S == 1 || (d & 1) == 0) {
+                        const int slot = (((S == 1 ? d : d / 2) % NSLOT) + NSLOT) % NSLOT;
+                        const int o2 = t - (KS - 1);
+                        if (o2 >= 0) {
+                            const int o = o2 / S;
+                            if (o < nrows) {
+                                const size_t eoff = (((size_t)n * p.Ho + ho_begin + o) * p.Wo + wo) * p.C + c0;
+                                float v[CPT];
+#pragma unroll
+                                for (int e = 0; e < NV; ++e) {
+                                    f32x2 t2 = sf[e];
+                                    pk_fma_acc(t2, acc[slot][e], sc[e]);
+                                    v[2 * e] = t2[0];
+                                    v[2 * e + 1] = t2[1];
+                                }
+                                if constexpr (FAST) clampn(v, act); else apply_actn(v, act);
+                                if (p.res != nullptr) {
+                                    float r4[CPT];
+                                    loadn<DT, CPT>(p.res, eoff, r4);
+#pragma unroll
+                                    for (int e = 0; e < CPT; ++e) v[e] += r4[e];
+                                }
+                                if (p.post_act != PCV_ACT_NONE) {
+                                    if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
+                                }
+                                storen<DT, CPT>(p.y, eoff, v);
+                            }
+#pragma unroll
+                            for (int e = 0; e < NV; ++e) acc[slot][e] = (f32x2){0.f, 0.f};
+                        }
+                    }
+                }
+                ++t;
+            }
+        });
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+

@@ -473,8 +473,8 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
 template <int DT, bool FAST> static void launch_dw2(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.kh == 3 && d.stride_h == 1) dwconv_kernel<DT, 3, 1, FAST><<<grid, 256, 0, s>>>(p);
     else if (d.kh == 3) dwconv_kernel<DT, 3, 2, FAST><<<grid, 256, 0, s>>>(p);
-    else if (d.stride_h == 1) dwconv_kernel<DT, 5, 1, FAST, 4><<<grid, 256, 0, s>>>(p);     // 5x5: 4 channels per thread
-    else dwconv_kernel<DT, 5, 2, FAST, 4><<<grid, 256, 0, s>>>(p);
+    else if (d.stride_h == 1) dwconv5_kernel<DT, 1, FAST><<<grid, 256, 0, s>>>(p);     // 5x5: row streaming, 4 channels per thread
+    else dwconv5_kernel<DT, 2, FAST><<<grid, 256, 0, s>>>(p);
 }
 template <int DT> static void launch_dw(const pcv_conv_desc& d, const DwParams& p, unsigned grid, hipStream_t s) {
     if (d.act <= PCV_ACT_RELU6 && d.post_act <= PCV_ACT_RELU6) launch_dw2<DT, true>(d, p, grid, s);
