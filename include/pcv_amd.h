@@ -88,8 +88,10 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value);
  * pad channels / pad columns zero-filled. */
 int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H, int W,
                      int cpitch, int wpitch, int dtype, void* stream);
-/* x: NHWC [N,H,W,C] in dtype -> y: fp32 NCHW (block-level drop-in use; not on the whole-net hot path). */
-int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream);
+/* x: NHWC [N,H,W,cpitch] in dtype (cpitch >= C: channels padded to a multiple of 8; 0 = C) -> y: fp32 NCHW [N,C,H,W]
+ * (block-level drop-in use; not on the whole-net hot path). */
+int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int cpitch, int dtype,
+                     void* stream);
 
 /* Decoded uint8 frames [N,Hs,Ws,C] (C <= 4) -> the network's input: crop [top, top+H) x [left, left+W), (u8/255 - mean[c]) *
  * inv_std[c] (the "ordinary normalization" every pretrained model expects, README.md:12-13), NHWC [N,H,wpitch,4] in dtype with

@@ -39,7 +39,7 @@ _SIGS = {
     "pcv_last_error": (ctypes.c_char_p, [_VP]),
     "pcv_set_tuning": (_I, [_VP, ctypes.c_char_p, _I]),
     "pcv_nchw_to_nhwc": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
-    "pcv_nhwc_to_nchw": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
+    "pcv_nhwc_to_nchw": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_preprocess_u8": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP]),
     "pcv_conv_packed_bytes": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_size_t)]),
     "pcv_conv_pack": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP]),

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 // NHWC [N,H,W,C] -> NCHW fp32 (block-level API only)
 template <int DT>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y,
-                                                          int N, int C, int H, int W) {
+                                                          int N, int C, int H, int W, int cpitch) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;         // over N*C*H*W, w fastest
     const long total = (long)N * C * H * W;
     if (i >= total) return;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     t /= H;
     const int c = (int)(t % C);
     const int n = (int)(t / C);
-    y[i] = load_elem<DT>(x, (((size_t)n * H + h) * W + w) * C + c);
+    y[i] = load_elem<DT>(x, (((size_t)n * H + h) * W + w) * cpitch + c);
 }
 
 // ---- weight packing (load time) ----------------------------------------------------------------------------

@@ -587,17 +587,18 @@ int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H,
     return PCV_OK;
 }
 
-int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int dtype, void* stream) {
+int pcv_nhwc_to_nchw(pcv_ctx* ctx, const void* x, float* y, int N, int C, int H, int W, int cpitch, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
-    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || !dtype_ok(dtype))
+    if (cpitch <= 0) cpitch = C;
+    if (!x || !y || N <= 0 || C <= 0 || H <= 0 || W <= 0 || cpitch < C || !dtype_ok(dtype))
         return fail(ctx, PCV_ERR_INVALID, "pcv_nhwc_to_nchw: bad argument");
     const long total = (long)N * C * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PCV_BF16) nhwc_to_nchw_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
-    else if (dtype == PCV_F16) nhwc_to_nchw_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
-    else nhwc_to_nchw_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W);
+    if (dtype == PCV_BF16) nhwc_to_nchw_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch);
+    else if (dtype == PCV_F16) nhwc_to_nchw_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch);
+    else nhwc_to_nchw_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

@@ -11,6 +11,7 @@ import os
 import ctypes
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from . import _lib
 from ._lib import ConvDesc
 
@@ -39,10 +40,16 @@ def compute_dtype_of(module: nn.Module) -> str:
     return getattr(module, "_pcv_dtype", None) or default_dtype()
 
 
+def round8(c: int) -> int:
+    return (int(c) + 7) // 8 * 8
+
+
 class NHWC(object):
     """
     An activation on the hot path: `t` is a contiguous device tensor [N, H, wpitch, cpitch]; (H, W, C) is the logical
-    extent. wpitch/cpitch differ from W/C only for the zero-padded network input (C <= 4 -> cpitch 4, W -> even).
+    extent. The kernels move 16-byte channel chunks, so the physical channel count `cpitch` is C rounded up to a multiple
+    of 8 (what the pad channels hold never reaches a logical channel: every weight that would read them is zero-padded).
+    The network input is the exception: C <= 4 -> cpitch 4, W -> even (the stem kernel's layout).
     """
     __slots__ = ("t", "N", "H", "W", "C", "wpitch", "cpitch")
 
@@ -61,7 +68,8 @@ class NHWC(object):
 
     @property
     def dense(self) -> bool:
-        return self.wpitch == self.W and self.cpitch == self.C
+        """Canonical internal layout: no row padding, channels padded to the next multiple of 8 only."""
+        return self.wpitch == self.W and self.cpitch == round8(self.C)
 
     def size(self, dim=None):
         s = (self.N, self.C, self.H, self.W)        # reported NCHW-style, as callers of the reference expect
@@ -73,7 +81,7 @@ class _ShapeOnly(object):
     __slots__ = ("N", "H", "W", "C", "dtype", "wpitch", "cpitch")
 
     def __init__(self, N, H, W, C, dtype):
-        self.N, self.H, self.W, self.C, self.dtype, self.wpitch, self.cpitch = N, H, W, C, dtype, W, C
+        self.N, self.H, self.W, self.C, self.dtype, self.wpitch, self.cpitch = N, H, W, C, dtype, W, round8(C)
 
 
 def _stream(device) -> ctypes.c_void_p:
@@ -111,11 +119,11 @@ def from_nchw(x: torch.Tensor, dtype: str, stem: bool = True) -> NHWC:
 
 def to_nchw(a: NHWC) -> torch.Tensor:
     """NHWC handle -> fp32 NCHW tensor (pcv_nhwc_to_nchw)."""
-    if not a.dense:
-        raise RuntimeError("cannot convert a padded input handle back to NCHW")
+    if a.wpitch != a.W:
+        raise RuntimeError("cannot convert a row-padded input handle back to NCHW")
     y = torch.empty((a.N, a.C, a.H, a.W), dtype=torch.float32, device=a.device)
     ctx = _ctx(a.device)
-    _lib.check(_lib.lib().pcv_nhwc_to_nchw(ctx, _ptr(a.t), _ptr(y), a.N, a.C, a.H, a.W, _CODE_OF_TORCH[a.dtype],
+    _lib.check(_lib.lib().pcv_nhwc_to_nchw(ctx, _ptr(a.t), _ptr(y), a.N, a.C, a.H, a.W, a.cpitch, _CODE_OF_TORCH[a.dtype],
                                            _stream(a.device)), ctx)
     return y
 
@@ -165,6 +173,18 @@ class ConvRunner(object):
         self._key = None
         self.packed = self.scale = self.shift = None
         self.depthwise = (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels)
+        if 1 < conv.groups and not self.depthwise and (conv.in_channels % 8 or conv.out_channels % 8):
+            raise NotImplementedError("grouped convolution with channel counts that are not multiples of 8")
+
+    def _phys(self, x_cpitch: int, out_fp32: bool):
+        """Physical (Cin, Cout, groups) the kernels run with: logical counts rounded up to multiples of 8, weights and BN
+        constants zero-padded accordingly in prepare(). Exceptions: the padded network input of the stem (cpitch 4) keeps the
+        logical Cin, and the fp32 classifier output keeps its logical width (ragged epilogue)."""
+        c = self.conv
+        cin = c.in_channels if x_cpitch == 4 and c.in_channels <= 4 else round8(c.in_channels)
+        cout = c.out_channels if out_fp32 else round8(c.out_channels)
+        groups = cin if self.depthwise else c.groups
+        return cin, cout, groups
 
     def _sources(self):
         ts = [self.conv.weight, self.conv.bias]
@@ -176,7 +196,7 @@ class ConvRunner(object):
         # pad4 is part of the key: the stem packing depends on the parity of the left padding (TF-"same" mode changes it)
         return (dtype, cpitch, self.pad4) + tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
 
-    def desc(self, x: NHWC, act, post_act, has_res, out_code=None) -> ConvDesc:
+    def desc(self, x: NHWC, act, post_act, has_res, out_code=None, logits=False) -> ConvDesc:
         c = self.conv
         kh, kw = _pair(c.kernel_size)
         sh, sw = _pair(c.stride)
@@ -188,8 +208,11 @@ class ConvRunner(object):
             pt = pb = ph
             pl = pr = pw
         code = _CODE_OF_TORCH[x.dtype]
-        d = ConvDesc(N=x.N, H=x.H, W=x.W, Cin=c.in_channels, Cout=c.out_channels, kh=kh, kw=kw, stride_h=sh, stride_w=sw,
-                     pad_t=pt, pad_l=pl, pad_b=pb, pad_r=pr, dil_h=dh, dil_w=dw, groups=c.groups, act=act, post_act=post_act,
+        cin, cout, groups = self._phys(x.cpitch, logits)          # `logits`: the fp32 classifier output keeps its logical width
+        if x.cpitch != cin and not (x.cpitch == 4 and cin <= 4):
+            raise RuntimeError("input handle has {} physical channels, this convolution expects {}".format(x.cpitch, cin))
+        d = ConvDesc(N=x.N, H=x.H, W=x.W, Cin=cin, Cout=cout, kh=kh, kw=kw, stride_h=sh, stride_w=sw,
+                     pad_t=pt, pad_l=pl, pad_b=pb, pad_r=pr, dil_h=dh, dil_w=dw, groups=groups, act=act, post_act=post_act,
                      has_residual=1 if has_res else 0, dtype=code, out_dtype=code if out_code is None else out_code,
                      x_cpitch=x.cpitch, x_wpitch=x.wpitch)
         return d
@@ -211,20 +234,31 @@ class ConvRunner(object):
             raise _lib.PcvError(-1, "unsupported convolution configuration: {}".format(
                 {f[0]: getattr(d, f[0]) for f in d._fields_}))
         packed = torch.empty((nbytes.value + 15) // 16 * 16, dtype=torch.uint8, device=dev)
-        w32 = w.detach().float().contiguous()
+        w32 = w.detach().float()
+        if w32.dim() == 2:                                          # nn.Linear viewed as a 1x1 convolution
+            w32 = w32[:, :, None, None]
+        C, Cl = d.Cout, self.conv.out_channels                      # physical / logical output channels
+        cin_g = d.Cin // d.groups                                   # physical input channels per group
+        if w32.shape[0] != C or w32.shape[1] != cin_g:              # zero rows / columns for the pad channels
+            w32 = F.pad(w32, (0, 0, 0, 0, 0, cin_g - w32.shape[1], 0, C - w32.shape[0]))
+        w32 = w32.contiguous()
         fn_pack = L.pcv_dwconv_pack if self.depthwise else L.pcv_conv_pack
         _lib.check(fn_pack(ctx, ctypes.byref(d), _ptr(w32), _ptr(packed), st), ctx)
-        C = self.conv.out_channels
+
+        def padded(t, fill):
+            t = t.detach().float()
+            return (F.pad(t, (0, C - Cl), value=fill) if C != Cl else t).contiguous()
         scale = torch.empty(C, dtype=torch.float32, device=dev)
         shift = torch.empty(C, dtype=torch.float32, device=dev)
-        bias = self.conv.bias.detach().float().contiguous() if self.conv.bias is not None else None
+        bias = padded(self.conv.bias, 0.0) if self.conv.bias is not None else None
         if self.bn is not None:
             if not isinstance(self.bn, nn.BatchNorm2d):
                 raise NotImplementedError("only BatchNorm2d folds into the conv epilogue, got {}".format(type(self.bn).__name__))
-            g = self.bn.weight.detach().float().contiguous() if self.bn.weight is not None else torch.ones(C, device=dev)
-            b = self.bn.bias.detach().float().contiguous() if self.bn.bias is not None else torch.zeros(C, device=dev)
-            m = self.bn.running_mean.detach().float().contiguous()
-            v = self.bn.running_var.detach().float().contiguous()
+            # pad channels: gamma 0, beta 0 -> scale 0, shift 0
+            g = padded(self.bn.weight, 0.0) if self.bn.weight is not None else padded(torch.ones(Cl, device=dev), 0.0)
+            b = padded(self.bn.bias, 0.0) if self.bn.bias is not None else torch.zeros(C, device=dev)
+            m = padded(self.bn.running_mean, 0.0)
+            v = padded(self.bn.running_var, 1.0)
             _lib.check(L.pcv_bn_fold(ctx, C, _ptr(g), _ptr(b), _ptr(m), _ptr(v), ctypes.c_float(self.bn.eps), _ptr(bias),
                                      _ptr(scale), _ptr(shift), st), ctx)
         else:
@@ -240,7 +274,7 @@ class ConvRunner(object):
             self.pad4 = tuple(int(v) for v in pad4)
         if self.bn is not None and self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
-        d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None)
+        d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None, logits=out_fp32)
         self.prepare(x, d)
         return self._launch(x, d, residual, out)
 
@@ -257,17 +291,17 @@ class ConvRunner(object):
         d2 = nxt.desc(_ShapeOnly(x.N, x.H, x.W, c.out_channels, x.dtype), nxt_act, 0, False)
         if not L.pcv_conv1x1_pair_supported(ctypes.byref(d1), ctypes.byref(d2)):
             return None
-        if not residual.dense or residual.dtype != x.dtype or tuple(residual.t.shape) != (x.N, x.H, x.W, c.out_channels):
+        if not residual.dense or residual.dtype != x.dtype or tuple(residual.t.shape) != (x.N, x.H, x.W, d1.Cout):
             raise RuntimeError("residual shape/dtype mismatch")
-        t1 = torch.empty((x.N, x.H, x.W, c.out_channels), dtype=x.dtype, device=x.device)
-        t2 = torch.empty((x.N, x.H, x.W, nxt.conv.out_channels), dtype=x.dtype, device=x.device)
-        y1 = NHWC(t1, x.N, x.H, x.W, c.out_channels)
+        t1 = torch.empty((x.N, x.H, x.W, d1.Cout), dtype=x.dtype, device=x.device)
+        t2 = torch.empty((x.N, x.H, x.W, d2.Cout), dtype=x.dtype, device=x.device)
+        y1 = NHWC(t1, x.N, x.H, x.W, c.out_channels, cpitch=d1.Cout)
         self.prepare(x, d1)
         nxt.prepare(y1, d2)
         _lib.check(L.pcv_conv1x1_pair_fused(ctx, ctypes.byref(d1), ctypes.byref(d2), _ptr(x.t), _ptr(self.packed),
                                             _ptr(self.scale), _ptr(self.shift), _ptr(residual.t), _ptr(t1), _ptr(nxt.packed),
                                             _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
-        return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels)
+        return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels, cpitch=d2.Cout)
 
     def _launch(self, x: NHWC, d: ConvDesc, residual, out=None):
         """`out` = (tensor [N, Ho, Wo, Ctot], channel offset): write the result into that channel slice of a wider
@@ -282,18 +316,18 @@ class ConvRunner(object):
         if out is not None:
             buf, coff = out
             if self.depthwise or tuple(buf.shape[:3]) != (x.N, Ho, Wo) or buf.dtype != out_dt or not buf.is_contiguous() or \
-                    coff % 8 != 0 or coff + c.out_channels > buf.shape[3] or buf.device != x.device:
-                raise RuntimeError("bad concatenation slice for a convolution output")
+                    coff % 8 != 0 or c.out_channels % 8 != 0 or coff + c.out_channels > buf.shape[3] or buf.device != x.device:
+                raise RuntimeError("bad concatenation slice for a convolution output (channel counts must be multiples of 8)")
             d.y_cpitch = int(buf.shape[3])
             y = buf[:, :, :, coff:]                 # a view: its data_ptr is the first element of the slice
         else:
-            y = torch.empty((x.N, Ho, Wo, c.out_channels), dtype=out_dt, device=x.device)
+            y = torch.empty((x.N, Ho, Wo, d.Cout), dtype=out_dt, device=x.device)          # d.Cout: physical channels
         if residual is not None:
-            if not residual.dense or tuple(residual.t.shape) != (x.N, Ho, Wo, c.out_channels) or residual.dtype != x.dtype:
+            if not residual.dense or tuple(residual.t.shape) != (x.N, Ho, Wo, d.Cout) or residual.dtype != x.dtype:
                 raise RuntimeError("residual shape/dtype mismatch: {} vs {}".format(
-                    tuple(residual.t.shape), (x.N, Ho, Wo, c.out_channels)))
+                    tuple(residual.t.shape), (x.N, Ho, Wo, d.Cout)))
         self._launch_range(x, d, residual, y, 0, x.N)
-        return None if out is not None else NHWC(y, x.N, Ho, Wo, c.out_channels)
+        return None if out is not None else NHWC(y, x.N, Ho, Wo, c.out_channels, cpitch=d.Cout)
 
     def _launch_range(self, x, d, residual, y, n0, n1):
         """Launch images [n0, n1); halve the range when one launch would exceed the 2 GiB addressing window."""
@@ -314,11 +348,11 @@ def maxpool2d(x: NHWC, k: int, s: int, p: int) -> NHWC:
     if not x.dense:
         raise RuntimeError("max-pool on a padded handle")
     Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
-    y = torch.empty((x.N, Ho, Wo, x.C), dtype=x.dtype, device=x.device)
+    y = torch.empty((x.N, Ho, Wo, x.cpitch), dtype=x.dtype, device=x.device)
     ctx = _ctx(x.device)
-    _lib.check(_lib.lib().pcv_maxpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, p, _CODE_OF_TORCH[x.dtype],
+    _lib.check(_lib.lib().pcv_maxpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.cpitch, k, s, p, _CODE_OF_TORCH[x.dtype],
                                         _stream(x.device)), ctx)
-    return NHWC(y, x.N, Ho, Wo, x.C)
+    return NHWC(y, x.N, Ho, Wo, x.C, cpitch=x.cpitch)
 
 
 def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
@@ -327,11 +361,11 @@ def avgpool2d(x: NHWC, k: int, s: int) -> NHWC:
     if k > x.H or k > x.W:
         raise RuntimeError("AvgPool2d kernel {} larger than the {}x{} map".format(k, x.H, x.W))
     Ho, Wo = (x.H - k) // s + 1, (x.W - k) // s + 1
-    y = torch.empty((x.N, Ho, Wo, x.C), dtype=x.dtype, device=x.device)
+    y = torch.empty((x.N, Ho, Wo, x.cpitch), dtype=x.dtype, device=x.device)
     ctx = _ctx(x.device)
     code = _CODE_OF_TORCH[x.dtype]
-    _lib.check(_lib.lib().pcv_avgpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.C, k, s, code, code, _stream(x.device)), ctx)
-    return NHWC(y, x.N, Ho, Wo, x.C)
+    _lib.check(_lib.lib().pcv_avgpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.cpitch, k, s, code, code, _stream(x.device)), ctx)
+    return NHWC(y, x.N, Ho, Wo, x.C, cpitch=x.cpitch)
 
 
 # Unit-level fusions (pcv_mbconv_fused, pcv_conv1x1_pair_fused) can be switched off to time the per-layer kernels on their own
@@ -363,7 +397,7 @@ def mbconv_fused(exp, exp_act: int, dw, dw_act: int, proj, proj_act: int, x: NHW
     d_proj = proj.desc(mid, proj_act, post_act, residual is not None)
     if not L.pcv_mbconv_supported(ctypes.byref(d_exp) if d_exp is not None else None, ctypes.byref(d_dw), ctypes.byref(d_proj)):
         return None
-    Cout = proj.conv.out_channels
+    Cout = d_proj.Cout                                           # physical
     if residual is not None and (not residual.dense or residual.dtype != x.dtype or
                                  tuple(residual.t.shape) != (x.N, Ho, Wo, Cout)):
         raise RuntimeError("residual shape/dtype mismatch")
@@ -378,7 +412,7 @@ def mbconv_fused(exp, exp_act: int, dw, dw_act: int, proj, proj_act: int, x: NHW
                                   _ptr(exp.scale) if exp is not None else None, _ptr(exp.shift) if exp is not None else None,
                                   _ptr(dw.packed), _ptr(dw.scale), _ptr(dw.shift), _ptr(proj.packed), _ptr(proj.scale),
                                   _ptr(proj.shift), _ptr(residual.t) if residual is not None else None, _ptr(y), st), ctx)
-    return NHWC(y, x.N, Ho, Wo, Cout)
+    return NHWC(y, x.N, Ho, Wo, proj.conv.out_channels, cpitch=Cout)
 
 
 class _PrepHandle(object):
@@ -410,12 +444,17 @@ class BnActRunner(object):
             raise NotImplementedError("only BatchNorm2d folds to scale/shift, got {}".format(type(bn).__name__))
         if bn.running_mean.device != dev:
             raise RuntimeError("model parameters are on {} but the input is on {}".format(bn.running_mean.device, dev))
-        C = bn.num_features
+        Cl = bn.num_features
+        C = round8(Cl)                                          # pad channels: scale 0, shift 0
+
+        def padded(t, fill):
+            t = t.detach().float()
+            return (F.pad(t, (0, C - Cl), value=fill) if C != Cl else t).contiguous()
         L, ctx, st = _lib.lib(), _ctx(dev), _stream(dev)
-        g = bn.weight.detach().float().contiguous() if bn.weight is not None else torch.ones(C, device=dev)
-        b = bn.bias.detach().float().contiguous() if bn.bias is not None else torch.zeros(C, device=dev)
-        m = bn.running_mean.detach().float().contiguous()
-        v = bn.running_var.detach().float().contiguous()
+        g = padded(bn.weight if bn.weight is not None else torch.ones(Cl, device=dev), 0.0)
+        b = padded(bn.bias if bn.bias is not None else torch.zeros(Cl, device=dev), 0.0)
+        m = padded(bn.running_mean, 0.0)
+        v = padded(bn.running_var, 1.0)
         scale = torch.empty(C, dtype=torch.float32, device=dev)
         shift = torch.empty(C, dtype=torch.float32, device=dev)
         _lib.check(L.pcv_bn_fold(ctx, C, _ptr(g), _ptr(b), _ptr(m), _ptr(v), ctypes.c_float(bn.eps), None, _ptr(scale),
@@ -431,22 +470,23 @@ class BnActRunner(object):
         if x.C != self.bn.num_features:
             raise RuntimeError("BatchNorm2d expects {} channels, got {}".format(self.bn.num_features, x.C))
         self.prepare(x)
-        y = torch.empty((x.N, x.H, x.W, x.C), dtype=x.dtype, device=x.device)
+        CP = round8(x.C)                        # physical channels processed (x may also be the prefix of a wider concat buffer)
+        y = torch.empty((x.N, x.H, x.W, CP), dtype=x.dtype, device=x.device)
         ctx = _ctx(x.device)
-        _lib.check(_lib.lib().pcv_bn_act(ctx, _ptr(x.t), _ptr(self.scale), _ptr(self.shift), _ptr(y), x.N * x.H * x.W, x.C,
+        _lib.check(_lib.lib().pcv_bn_act(ctx, _ptr(x.t), _ptr(self.scale), _ptr(self.shift), _ptr(y), x.N * x.H * x.W, CP,
                                          x.cpitch, act, _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
-        return NHWC(y, x.N, x.H, x.W, x.C)
+        return NHWC(y, x.N, x.H, x.W, x.C, cpitch=CP)
 
 
 def global_avgpool(x: NHWC) -> NHWC:
     """nn.AdaptiveAvgPool2d(1) -> [N,1,1,C]."""
     if not x.dense:
         raise RuntimeError("avg-pool on a padded handle")
-    y = torch.empty((x.N, 1, 1, x.C), dtype=x.dtype, device=x.device)
+    y = torch.empty((x.N, 1, 1, x.cpitch), dtype=x.dtype, device=x.device)
     ctx = _ctx(x.device)
     code = _CODE_OF_TORCH[x.dtype]
-    _lib.check(_lib.lib().pcv_global_avgpool(ctx, _ptr(x.t), _ptr(y), x.N, x.H * x.W, x.C, code, code, _stream(x.device)), ctx)
-    return NHWC(y, x.N, 1, 1, x.C)
+    _lib.check(_lib.lib().pcv_global_avgpool(ctx, _ptr(x.t), _ptr(y), x.N, x.H * x.W, x.cpitch, code, code, _stream(x.device)), ctx)
+    return NHWC(y, x.N, 1, 1, x.C, cpitch=x.cpitch)
 
 
 def se_forward(x: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int, residual: NHWC | None, post_act: int) -> NHWC:
@@ -455,16 +495,21 @@ def se_forward(x: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int, residual: NH
         raise RuntimeError("SE on a padded handle")
     L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
     code = _CODE_OF_TORCH[x.dtype]
-    mean = torch.empty((x.N, x.C), dtype=torch.float32, device=x.device)
-    gate = torch.empty((x.N, x.C), dtype=torch.float32, device=x.device)
-    _lib.check(L.pcv_se_squeeze(ctx, _ptr(x.t), _ptr(mean), x.N, x.H * x.W, x.C, code, st), ctx)
+    CP = x.cpitch                                              # physical channels; the FC weights get zero columns / rows for the pads
+    if CP != x.C:
+        w1 = F.pad(w1, (0, CP - x.C)).contiguous()
+        w2 = F.pad(w2, (0, 0, 0, CP - x.C)).contiguous()
+        b2 = F.pad(b2, (0, CP - x.C)).contiguous()
+    mean = torch.empty((x.N, CP), dtype=torch.float32, device=x.device)
+    gate = torch.empty((x.N, CP), dtype=torch.float32, device=x.device)
+    _lib.check(L.pcv_se_squeeze(ctx, _ptr(x.t), _ptr(mean), x.N, x.H * x.W, CP, code, st), ctx)
     M = w1.shape[0]
     mid = torch.empty((x.N, M), dtype=torch.float32, device=x.device)
-    _lib.check(L.pcv_se_excite(ctx, _ptr(mean), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mid), _ptr(gate), x.N, x.C, M,
+    _lib.check(L.pcv_se_excite(ctx, _ptr(mean), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(mid), _ptr(gate), x.N, CP, M,
                                mid_act, out_act, st), ctx)
     y = torch.empty_like(x.t)
     if residual is not None and (residual.t.shape != x.t.shape or residual.dtype != x.dtype):
         raise RuntimeError("SE residual shape/dtype mismatch")
     _lib.check(L.pcv_se_scale(ctx, _ptr(x.t), _ptr(gate), _ptr(residual.t) if residual is not None else None, _ptr(y),
-                              x.N, x.H * x.W, x.C, post_act, code, st), ctx)
-    return NHWC(y, x.N, x.H, x.W, x.C)
+                              x.N, x.H * x.W, CP, post_act, code, st), ctx)
+    return NHWC(y, x.N, x.H, x.W, x.C, cpitch=CP)

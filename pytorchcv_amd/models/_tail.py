@@ -75,22 +75,16 @@ class _LinearAsConv(object):
 
 
 def check_channels(net: nn.Module):
-    """The MI355X kernels move activations in 16-byte NHWC chunks: every internal channel count must be a multiple of 8 (the
-    network input and the classifier output are exempt - padded stem, ragged epilogue; SE layers are fp32 FCs of any width).
-    A variant that breaks this (the narrow MobileNetV2 widths) still constructs and loads weights like the reference's, but
-    its forward is refused up front with the offending layer named, not somewhere inside the first launch."""
+    """The MI355X kernels move activations in 16-byte NHWC chunks; channel counts that are not multiples of 8 run with
+    zero-padded weights (engine.ConvRunner). The one thing padding cannot express is a grouped (non-depthwise) convolution
+    whose channels are not multiples of 8: such a net is refused up front, with the layer named."""
     if getattr(net, "_pcv_channels_ok", False):
         return
-    from .common.att import SEBlock
-    se_prefixes = tuple(n + "." for n, m in net.named_modules() if isinstance(m, SEBlock))
-    convs = [(n, m) for n, m in net.named_modules() if isinstance(m, nn.Conv2d) and not n.startswith(se_prefixes)]
-    for i, (n, m) in enumerate(convs):
-        cin_ok = m.in_channels % 8 == 0 or (i == 0 and m.in_channels <= 4)
-        cout_ok = m.out_channels % 8 == 0 or n.startswith("output")
-        if not (cin_ok and cout_ok):
-            raise NotImplementedError(
-                "{}: layer {} has {} -> {} channels; the MI355X path needs multiples of 8 (this width variant is not supported "
-                "yet)".format(type(net).__name__, n, m.in_channels, m.out_channels))
+    for n, m in net.named_modules():
+        if isinstance(m, nn.Conv2d) and 1 < m.groups and not (m.groups == m.in_channels == m.out_channels) and \
+                (m.in_channels % 8 or m.out_channels % 8):
+            raise NotImplementedError("{}: grouped convolution {} has {} -> {} channels in {} groups; the MI355X path needs "
+                                      "multiples of 8 there".format(type(net).__name__, n, m.in_channels, m.out_channels, m.groups))
     net._pcv_channels_ok = True
 
 

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 _NETS = [
     ("resnet10", 224, True), ("resnetbc14b", 224, True), ("resnet34", 224, True), ("resnet152b", 224, False),
     ("mobilenet_wd2", 224, True), ("mobilenet_w3d4", 224, True),
+    ("mobilenetv2_wd4", 224, True), ("mobilenetv2_wd2", 224, True), ("mobilenetv2_w3d4", 224, True),   # channel counts 4, 6, 12, 18 ...
     ("mobilenetv3_small_w7d20", 224, True), ("mobilenetv3_large_w5d4", 224, True),
     ("efficientnet_b1", 240, True), ("efficientnet_b3b", 300, True), ("efficientnet_b5c", 456, False),
     ("resnext50_32x4d", 224, True), ("resnext101_64x4d", 224, False), ("seresnet18", 224, True), ("seresnext101_32x4d", 224, False),
@@ -44,10 +45,34 @@ def test_registry_model_runs_and_matches_oracle(name, size, check, cuda_device):
         assert err <= 5e-3 * max(1.0, float(ref.abs().max())), (name, err)
 
 
-def test_unsupported_width_variants_are_refused_before_any_launch(cuda_device):
-    """They construct (state_dict / parameter count like the reference's) but their forward names the offending layer."""
-    from pytorchcv_amd.model_provider import get_model
-    for name in ("mobilenetv2_wd4", "mobilenetv2_wd2", "mobilenetv2_w3d4"):
-        net = get_model(name).eval().to(cuda_device)
-        with pytest.raises(NotImplementedError, match="multiples of 8"):
-            net(torch.zeros(1, 3, 224, 224, device=cuda_device))
+def test_odd_channel_blocks_are_padded_not_refused(cuda_device):
+    """Channel counts that are not multiples of 8 run with zero-padded weights; block-level results (incl. the NCHW round
+    trip, SE, depthwise, residual) match the oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
+    from pytorchcv_amd.models.common.att import SEBlock
+    from pytorchcv_amd.models.common.activ import lambda_relu6
+    unit = LinearBottleneck(in_channels=12, out_channels=12, stride=1, expansion=True, remove_exp_conv=False,
+                            activation=lambda_relu6()).eval()
+    sd = util.synth_state_dict(unit.state_dict(), seed=41)
+    unit.load_state_dict(sd)
+    unit = pytorchcv_amd.set_compute_dtype(unit.to(cuda_device), "fp32")
+    x = util.synth_input(2, 12, 20, 28, seed=42)
+    with torch.no_grad():
+        y = unit(x.to(cuda_device)).cpu()
+    sdc = {k: v.float() for k, v in sd.items()}
+    t = refnet.conv_block(sdc, "conv1.", x, act="relu6")
+    t = refnet.conv_block(sdc, "conv2.", t, padding=1, groups=t.shape[1], act="relu6")
+    ref = refnet.conv_block(sdc, "conv3.", t, act=None, residual=x)
+    assert y.shape == ref.shape == (2, 12, 20, 28)
+    assert float((y - ref).abs().max()) <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+    se = SEBlock(channels=20, reduction=4).eval()
+    sd = util.synth_state_dict(se.state_dict(), seed=43)
+    se.load_state_dict(sd)
+    se = pytorchcv_amd.set_compute_dtype(se.to(cuda_device), "fp32")
+    x = util.synth_input(2, 20, 7, 7, seed=44)
+    with torch.no_grad():
+        y = se(x.to(cuda_device)).cpu()
+    ref = refnet.se_block({k: v.float() for k, v in sd.items()}, "", x)
+    assert float((y - ref).abs().max()) <= 1e-4
