@@ -121,9 +121,18 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
 /* Depthwise direct convolution, fused epilogue (same contract). */
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
                        const float* scale, const float* shift, const void* residual, void* y, void* stream);
-/* nn.MaxPool2d(k, s, p) of ResInitBlock (resnet.py:255-258); -inf padding, floor output size. */
+/* nn.MaxPool2d(k, s, p, ceil_mode) of ResInitBlock (resnet.py:255-258, floor) and ShuffleInitBlock (shufflenetv2.py:111-115,
+ * ceil_mode=True): -inf padding; with ceil_mode the last window may hang over the bottom / right edge (PyTorch's rule). */
 int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p,
-                  int dtype, void* stream);
+                  int ceil_mode, int dtype, void* stream);
+/* torch.chunk / channel slicing at ANY channel offset (shufflenetv2.py:80): y[rows, y_cpitch] gets x[.., offset .. offset+C),
+ * pad channels zero. */
+int pcv_channel_slice(pcv_ctx* ctx, const void* x, void* y, long rows, int C, int offset, int x_cpitch, int y_cpitch,
+                      int dtype, void* stream);
+/* torch.cat((a, b), dim=1) + ChannelShuffle(groups=2) (shufflenetv2.py:89-90, common/tutti.py:267-291) in one pass:
+ * y[.., 2i] = a[.., i], y[.., 2i+1] = b[.., i], i < Ch. */
+int pcv_channel_interleave2(pcv_ctx* ctx, const void* a, const void* b, void* y, long rows, int Ch, int a_cpitch,
+                            int b_cpitch, int y_cpitch, int dtype, void* stream);
 /* nn.AvgPool2d(k, stride=s), no padding (resnet.py:316-318, mobilenetv2.py:134-136); k == H == W is the
  * global-average-pool of the classifier tail. fp32 accumulation. */
 int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s,

@@ -7,7 +7,8 @@
     (SEBlock), resnet.py:143-263 (ResUnit, ResInitBlock), mobilenetv2.py:16-71 (LinearBottleneck), resnext.py:17-116
     (ResNeXtUnit), seresnet.py:17-72 (SEResUnit), mobilenetv3.py:18-93 (MobileNetV3Unit),
     efficientnet.py:58-239 (EffiDwsConvUnit, EffiInvResUnit, EffiInitBlock), conv.py:652-810 (PreConvBlock),
-    preresnet.py:109-222 (PreResUnit, PreResInitBlock, PreResActivation), densenet.py:16-91 (DenseUnit, TransitionBlock).
+    preresnet.py:109-222 (PreResUnit, PreResInitBlock, PreResActivation), densenet.py:16-91 (DenseUnit, TransitionBlock),
+    shufflenetv2.py:17-120 (ShuffleUnit, ShuffleInitBlock).
 """
 
 __all__ = ['block_forward']
@@ -15,7 +16,7 @@ __all__ = ['block_forward']
 import torch
 import torch.nn.functional as F
 from .refnet import (Quant, conv_block, se_block, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit, bn_act,
-                     pre_conv_chain, preres_unit, preres_init_block, dense_unit, dense_transition)
+                     pre_conv_chain, preres_unit, preres_init_block, dense_unit, dense_transition, shuffle_unit)
 
 _KSIZE = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv5x5_block": (5, 2), "conv7x7_block": (7, 3),
           "dwconv3x3_block": (3, 1), "dwconv5x5_block": (5, 2)}
@@ -87,6 +88,11 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
             return preres_init_block(sd, "", x, q)
         if kind == "PreResActivation":
             return bn_act(sd, "bn.", x, q)
+        if kind == "ShuffleUnit":
+            return shuffle_unit(sd, "", x, kw["downsample"], q)
+        if kind == "ShuffleInitBlock":
+            y = conv_block(sd, "conv.", x, stride=2, padding=1, q=q)
+            return F.max_pool2d(y, kernel_size=3, stride=2, padding=0, ceil_mode=True)
         if kind == "DenseUnit":
             return dense_unit(sd, "", x, q)
         if kind == "TransitionBlock":

@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'shufflenetv2_forward', 'shuffle_unit', 'channel_shuffle', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -499,6 +499,60 @@ def densenet_forward(sd, x, q=None, taps=None):
     return _classifier(sd, x, q)
 
 
+def _conv_bn(sd, conv_p, bn_p, x, q, stride=1, padding=0, groups=1, act=None, eps=1e-5):
+    """Bare Conv2d followed by a stand-alone BatchNorm2d (+ activation), as ShuffleUnit spells it (shufflenetv2.py:71-88); the GPU
+    path fuses the three, so the quantised mode rounds once."""
+    w = sd[conv_p + "weight"].float()
+    if q.on:
+        y = F.conv2d(x, q.r(w), None, stride, padding, 1, groups)
+        scale, shift = fold_bn(sd, bn_p, eps)
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    else:
+        y = F.conv2d(x, w, None, stride, padding, 1, groups)
+        y = F.batch_norm(y, sd[bn_p + "running_mean"], sd[bn_p + "running_var"], sd[bn_p + "weight"], sd[bn_p + "bias"],
+                         False, 0.0, eps)
+    return q.r(_act(y, act))
+
+
+def channel_shuffle(x, groups):
+    """common/tutti.py:267-291."""
+    b, c, h, w = x.shape
+    return x.view(b, groups, c // groups, h, w).transpose(1, 2).contiguous().view(b, c, h, w)
+
+
+def shuffle_unit(sd, p, x, downsample, q=None):
+    """ShuffleUnit.forward (shufflenetv2.py:69-91), use_se / use_residual False as in the registry models."""
+    q = q or Quant(None)
+    if downsample:
+        y1 = _conv_bn(sd, p + "dw_conv4.", p + "dw_bn4.", x, q, stride=2, padding=1, groups=x.shape[1])
+        y1 = _conv_bn(sd, p + "expand_conv5.", p + "expand_bn5.", y1, q, act="relu")
+        x2 = x
+    else:
+        y1, x2 = torch.chunk(x, chunks=2, dim=1)
+    y2 = _conv_bn(sd, p + "compress_conv1.", p + "compress_bn1.", x2, q, act="relu")
+    y2 = _conv_bn(sd, p + "dw_conv2.", p + "dw_bn2.", y2, q, stride=(2 if downsample else 1), padding=1, groups=y2.shape[1])
+    y2 = _conv_bn(sd, p + "expand_conv3.", p + "expand_bn3.", y2, q, act="relu")
+    return channel_shuffle(torch.cat((y1, y2), dim=1), 2)
+
+
+def shufflenetv2_forward(sd, x, q=None, taps=None):
+    """ShuffleNetV2.forward (shufflenetv2.py:176-180); ShuffleInitBlock (:117-120) with MaxPool2d(3, 2, 0, ceil_mode=True)."""
+    q = q or Quant(None)
+    x = conv_block(sd, "features.init_block.conv.", q.r(x), stride=2, padding=1, q=q)
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=0, ceil_mode=True)
+    _tap(taps, "init_block", x)
+    i = 0
+    while ("features.stage{}.unit1.compress_conv1.weight".format(i + 1)) in sd:
+        j = 0
+        while ("features.stage{}.unit{}.compress_conv1.weight".format(i + 1, j + 1)) in sd:
+            x = shuffle_unit(sd, "features.stage{}.unit{}.".format(i + 1, j + 1), x, downsample=(j == 0), q=q)
+            j += 1
+        _tap(taps, "stage{}".format(i + 1), x)
+        i += 1
+    x = conv_block(sd, "features.final_block.", x, q=q)
+    return _classifier(sd, x, q)
+
+
 def tf_same_pad(h, w, kernel_size, stride=1, dilation=1):
     """calc_tf_padding, efficientnet.py:27-55. Returned in F.pad order: the reference hands (pad_h//2, pad_h - pad_h//2,
     pad_w//2, pad_w - pad_w//2) to F.pad, which reads it as (left, right, top, bottom)."""
@@ -607,6 +661,8 @@ for _n, _kw in {"preresnet10": dict(blocks=10), "preresnet12": dict(blocks=12), 
     MODEL_ARCH[_n] = ("preresnet", _kw)
     if _n != "preresnet269b":
         MODEL_ARCH["se" + _n] = ("preresnet", _kw)          # SE-PreResNet: same trunk, `se.` blocks in the state_dict
+for _n in ("shufflenetv2_wd2", "shufflenetv2_w1", "shufflenetv2_w3d2", "shufflenetv2_w2"):
+    MODEL_ARCH[_n] = ("shufflenetv2", dict())
 for _n in ("densenet121", "densenet161", "densenet169", "densenet201"):
     MODEL_ARCH[_n] = ("densenet", dict())
 for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
@@ -618,7 +674,8 @@ for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
 _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnext": resnext_forward,
            "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
            "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward,
-           "preresnet": preresnet_forward, "densenet": densenet_forward}
+           "preresnet": preresnet_forward, "densenet": densenet_forward,
+           "shufflenetv2": shufflenetv2_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

@@ -48,7 +48,9 @@ _SIGS = {
     "pcv_bn_fold": (_I, [_VP, _I, _VP, _VP, _VP, _VP, ctypes.c_float, _VP, _VP, _VP, _VP]),
     "pcv_conv2d_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pcv_dwconv2d_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "pcv_maxpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "pcv_maxpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
+    "pcv_channel_slice": (_I, [_VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _I, _VP]),
+    "pcv_channel_interleave2": (_I, [_VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _I, _VP]),
     "pcv_avgpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_global_avgpool": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_gemm_bias": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),

@@ -384,3 +384,39 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
     }
 }
 
+// ---- channel plumbing of ShuffleNet-style units (shufflenetv2.py:69-91; common/tutti.py:267-291) ---------------------------------
+// torch.chunk(x, 2, dim=1)[1]: y[.., i] = x[.., off + i], i < C; y has `ypitch` physical channels, the pads are written as zero.
+// Channel offsets here are arbitrary (58 of 116), so this works element-wise: one thread = one pixel x 8 output channels.
+template <int DT>
+__global__ __launch_bounds__(256) void channel_slice_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int C,
+                                                           int off, int xpitch, int ypitch) {
+    const int P8 = ypitch / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * P8) return;
+    const long row = i / P8;
+    const int c0 = (int)(i - row * P8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? load_elem<DT>(x, (size_t)row * xpitch + off + c0 + e) : 0.f;
+    store8<DT>(y, (size_t)row * ypitch + c0, v);
+}
+// torch.cat((a, b), dim=1) followed by channel_shuffle(groups = 2): y[.., 2i] = a[.., i], y[.., 2i + 1] = b[.., i], i < Ch.
+template <int DT>
+__global__ __launch_bounds__(256) void channel_interleave2_kernel(const void* __restrict__ a, const void* __restrict__ b,
+                                                                 void* __restrict__ y, long rows, int Ch, int apitch, int bpitch,
+                                                                 int ypitch) {
+    const int P8 = ypitch / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * P8) return;
+    const long row = i / P8;
+    const int c0 = (int)(i - row * P8) * 8;          // even
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = c0 / 2 + e;
+        v[2 * e] = j < Ch ? load_elem<DT>(a, (size_t)row * apitch + j) : 0.f;
+        v[2 * e + 1] = j < Ch ? load_elem<DT>(b, (size_t)row * bpitch + j) : 0.f;
+    }
+    store8<DT>(y, (size_t)row * ypitch + c0, v);
+}
+

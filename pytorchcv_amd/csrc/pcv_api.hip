@@ -968,14 +968,20 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     return PCV_OK;
 }
 
-int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p, int dtype,
-                  void* stream) {
+static int pool_out(int in, int k, int s, int p, int ceil_mode) {
+    int o = ceil_mode ? (in + 2 * p - k + s - 1) / s + 1 : (in + 2 * p - k) / s + 1;
+    if (ceil_mode && (o - 1) * s >= in + p) --o;          // the last window must start inside the input or the left padding
+    return o;
+}
+
+int pcv_maxpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s, int p, int ceil_mode,
+                  int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
     if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || s <= 0 || p < 0 || !dtype_ok(dtype) || C % 8 != 0 ||
         2 * p > k)
         return fail(ctx, PCV_ERR_INVALID, "pcv_maxpool2d: bad argument (C must be a multiple of 8, pad <= k/2)");
-    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const int Ho = pool_out(H, k, s, p, ceil_mode), Wo = pool_out(W, k, s, p, ceil_mode);
     if (Ho <= 0 || Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_maxpool2d: empty output");
     const long total = (long)N * Ho * Wo * (C / 8);
     const unsigned grid = (unsigned)((total + 255) / 256);
@@ -1129,6 +1135,39 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2><<<grid, 256, pair_lds(2), st>>>(p);
         else pair1x1_kernel<PCV_F16, 2><<<grid, 256, pair_lds(2), st>>>(p);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_channel_slice(pcv_ctx* ctx, const void* x, void* y, long rows, int C, int offset, int x_cpitch, int y_cpitch, int dtype,
+                      void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !y || rows <= 0 || C <= 0 || offset < 0 || x_cpitch < offset + C || y_cpitch < C || y_cpitch % 8 != 0 || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_channel_slice: bad argument (y_cpitch must be a multiple of 8 and hold C channels)");
+    const long total = rows * (y_cpitch / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) channel_slice_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, rows, C, offset, x_cpitch, y_cpitch);
+    else if (dtype == PCV_F16) channel_slice_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, rows, C, offset, x_cpitch, y_cpitch);
+    else channel_slice_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, rows, C, offset, x_cpitch, y_cpitch);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_channel_interleave2(pcv_ctx* ctx, const void* a, const void* b, void* y, long rows, int Ch, int a_cpitch, int b_cpitch,
+                            int y_cpitch, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!a || !b || !y || rows <= 0 || Ch <= 0 || a_cpitch < Ch || b_cpitch < Ch || y_cpitch < 2 * Ch || y_cpitch % 8 != 0 ||
+        !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_channel_interleave2: bad argument (y_cpitch must be a multiple of 8 and hold 2*Ch channels)");
+    const long total = rows * (y_cpitch / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) channel_interleave2_kernel<PCV_BF16><<<grid, 256, 0, st>>>(a, b, y, rows, Ch, a_cpitch, b_cpitch, y_cpitch);
+    else if (dtype == PCV_F16) channel_interleave2_kernel<PCV_F16><<<grid, 256, 0, st>>>(a, b, y, rows, Ch, a_cpitch, b_cpitch, y_cpitch);
+    else channel_interleave2_kernel<PCV_F32><<<grid, 256, 0, st>>>(a, b, y, rows, Ch, a_cpitch, b_cpitch, y_cpitch);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

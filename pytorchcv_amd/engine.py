@@ -5,7 +5,8 @@
 """
 
 __all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'from_nchw', 'to_nchw', 'ConvRunner',
-           'BnActRunner', 'maxpool2d', 'avgpool2d', 'global_avgpool', 'se_forward', 'act_code', 'boundary']
+           'BnActRunner', 'maxpool2d', 'avgpool2d', 'global_avgpool', 'se_forward', 'channel_slice', 'cat_shuffle2', 'act_code',
+           'boundary', 'round8']
 
 import os
 import ctypes
@@ -344,14 +345,45 @@ class ConvRunner(object):
         _lib.check(rc, ctx)
 
 
-def maxpool2d(x: NHWC, k: int, s: int, p: int) -> NHWC:
+def _pool_out(n: int, k: int, s: int, p: int, ceil_mode: bool) -> int:
+    o = (n + 2 * p - k + (s - 1 if ceil_mode else 0)) // s + 1
+    if ceil_mode and (o - 1) * s >= n + p:
+        o -= 1
+    return o
+
+
+def channel_slice(x: NHWC, offset: int, count: int) -> NHWC:
+    """x[:, offset:offset+count] (channel dimension) as a canonical handle of its own (torch.chunk / split)."""
+    if x.wpitch != x.W or offset < 0 or offset + count > x.C:
+        raise RuntimeError("bad channel slice")
+    cp = round8(count)
+    y = torch.empty((x.N, x.H, x.W, cp), dtype=x.dtype, device=x.device)
+    ctx = _ctx(x.device)
+    _lib.check(_lib.lib().pcv_channel_slice(ctx, _ptr(x.t), _ptr(y), x.N * x.H * x.W, count, offset, x.cpitch, cp,
+                                            _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
+    return NHWC(y, x.N, x.H, x.W, count, cpitch=cp)
+
+
+def cat_shuffle2(a: NHWC, b: NHWC, half: int) -> NHWC:
+    """channel_shuffle(torch.cat((a[:, :half], b[:, :half]), dim=1), groups=2) in one pass."""
+    if (a.N, a.H, a.W) != (b.N, b.H, b.W) or a.dtype != b.dtype or a.wpitch != a.W or b.wpitch != b.W or half > a.C or half > b.C:
+        raise RuntimeError("cat/shuffle operands do not match")
+    cp = round8(2 * half)
+    y = torch.empty((a.N, a.H, a.W, cp), dtype=a.dtype, device=a.device)
+    ctx = _ctx(a.device)
+    _lib.check(_lib.lib().pcv_channel_interleave2(ctx, _ptr(a.t), _ptr(b.t), _ptr(y), a.N * a.H * a.W, half, a.cpitch, b.cpitch,
+                                                  cp, _CODE_OF_TORCH[a.dtype], _stream(a.device)), ctx)
+    return NHWC(y, a.N, a.H, a.W, 2 * half, cpitch=cp)
+
+
+def maxpool2d(x: NHWC, k: int, s: int, p: int, ceil_mode: bool = False) -> NHWC:
     if not x.dense:
         raise RuntimeError("max-pool on a padded handle")
-    Ho, Wo = (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1
+    Ho, Wo = _pool_out(x.H, k, s, p, ceil_mode), _pool_out(x.W, k, s, p, ceil_mode)
     y = torch.empty((x.N, Ho, Wo, x.cpitch), dtype=x.dtype, device=x.device)
     ctx = _ctx(x.device)
-    _lib.check(_lib.lib().pcv_maxpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.cpitch, k, s, p, _CODE_OF_TORCH[x.dtype],
-                                        _stream(x.device)), ctx)
+    _lib.check(_lib.lib().pcv_maxpool2d(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.cpitch, k, s, p, 1 if ceil_mode else 0,
+                                        _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
     return NHWC(y, x.N, Ho, Wo, x.C, cpitch=x.cpitch)
 
 

@@ -2,7 +2,7 @@
     `get_model(name, **kwargs)` with the reference's contract (pytorchcv/model_provider.py:1364-1382): case-insensitive
     name, `ValueError("Unsupported model: ...")` for unknown names, kwargs (`pretrained`, `root`, `in_channels`, `in_size`,
     `num_classes`) forwarded to the factory. The registry holds the families whose whole forward runs on the MI355X hot
-    path (ResNet, SE-ResNet, ResNeXt, SE-ResNeXt, MobileNet, MobileNetV2, MobileNetV3, EfficientNet, PreResNet, SE-PreResNet, DenseNet).
+    path (ResNet, SE-ResNet, ResNeXt, SE-ResNeXt, MobileNet, MobileNetV2, MobileNetV3, EfficientNet, PreResNet, SE-PreResNet, DenseNet, ShuffleNetV2).
 """
 
 __all__ = ['get_model']
@@ -18,9 +18,10 @@ from .models import efficientnet as _efficientnet
 from .models import preresnet as _preresnet
 from .models import sepreresnet as _sepreresnet
 from .models import densenet as _densenet
+from .models import shufflenetv2 as _shufflenetv2
 
 _models = {}
-for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet, _mobilenetv3, _efficientnet, _preresnet, _sepreresnet, _densenet):
+for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet, _mobilenetv3, _efficientnet, _preresnet, _sepreresnet, _densenet, _shufflenetv2):
     for _name in _mod.__all__:
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith(("get_", "calc_")) and callable(_fn):

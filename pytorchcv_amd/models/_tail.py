@@ -13,12 +13,12 @@ from .. import engine
 
 class MaxPool2dNHWC(nn.Module):
     """nn.MaxPool2d(kernel_size, stride, padding) of ResInitBlock (reference resnet.py:255-258) -> pcv_maxpool2d."""
-    def __init__(self, kernel_size, stride, padding):
+    def __init__(self, kernel_size, stride, padding, ceil_mode=False):
         super(MaxPool2dNHWC, self).__init__()
-        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.kernel_size, self.stride, self.padding, self.ceil_mode = kernel_size, stride, padding, ceil_mode
 
     def forward(self, x):
-        return engine.boundary(self, x, lambda a: engine.maxpool2d(a, self.kernel_size, self.stride, self.padding))
+        return engine.boundary(self, x, lambda a: engine.maxpool2d(a, self.kernel_size, self.stride, self.padding, self.ceil_mode))
 
 
 class AvgPool2dNHWC(nn.Module):

@@ -99,7 +99,7 @@ def make_model(ref_models, name):
            "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
            "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3",
            "efficientnet_b0": "efficientnet", "efficientnet_b0b": "efficientnet",
-           "preresnet18": "preresnet", "preresnet50": "preresnet", "sepreresnet18": "sepreresnet", "densenet121": "densenet"}[name]
+           "preresnet18": "preresnet", "preresnet50": "preresnet", "sepreresnet18": "sepreresnet", "densenet121": "densenet", "shufflenetv2_w1": "shufflenetv2"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 
@@ -153,6 +153,7 @@ def build_block(case):
     from pytorchcv.models.common.norm import lambda_batchnorm2d
     from pytorchcv.models.preresnet import PreResUnit, PreResInitBlock, PreResActivation
     from pytorchcv.models.densenet import DenseUnit, TransitionBlock
+    from pytorchcv.models.shufflenetv2 import ShuffleUnit, ShuffleInitBlock
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
@@ -166,7 +167,7 @@ def build_block(case):
             "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit,
             "pre_conv3x3_block": C.pre_conv3x3_block, "pre_conv1x1_block": C.pre_conv1x1_block, "PreResUnit": PreResUnit,
             "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation, "DenseUnit": DenseUnit,
-            "TransitionBlock": TransitionBlock}[kind]
+            "TransitionBlock": TransitionBlock, "ShuffleUnit": ShuffleUnit, "ShuffleInitBlock": ShuffleInitBlock}[kind]
     return ctor(**kw).eval()
 
 

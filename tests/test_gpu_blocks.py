@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 IDS = [c["name"] for c in util.BLOCK_CASES]
 # compound units: the fp32-golden comparison accumulates rounding over 3-4 chained convolutions
-_UNITS = ("ResUnit", "SEResUnit", "LinearBottleneck", "ResNeXtUnit", "ResInitBlock")
+_UNITS = ("ResUnit", "SEResUnit", "LinearBottleneck", "ResNeXtUnit", "ResInitBlock", "ShuffleUnit")   # several rounded layers deep
 
 
 def _run(case, dtype, dev):

@@ -57,6 +57,7 @@ def build_block(case):
     from pytorchcv_amd.models.common.norm import lambda_batchnorm2d
     from pytorchcv_amd.models.preresnet import PreResUnit, PreResInitBlock, PreResActivation
     from pytorchcv_amd.models.densenet import DenseUnit, TransitionBlock
+    from pytorchcv_amd.models.shufflenetv2 import ShuffleUnit, ShuffleInitBlock
     kind, kw = case["kind"], dict(case["kwargs"])
     if kind == "LinearBottleneck":
         kw["activation"] = lambda_relu6()
@@ -70,7 +71,7 @@ def build_block(case):
             "EffiInitBlock": EffiInitBlock, "EffiDwsConvUnit": EffiDwsConvUnit, "EffiInvResUnit": EffiInvResUnit,
             "pre_conv3x3_block": C.pre_conv3x3_block, "pre_conv1x1_block": C.pre_conv1x1_block, "PreResUnit": PreResUnit,
             "PreResInitBlock": PreResInitBlock, "PreResActivation": PreResActivation, "DenseUnit": DenseUnit,
-            "TransitionBlock": TransitionBlock}[kind]
+            "TransitionBlock": TransitionBlock, "ShuffleUnit": ShuffleUnit, "ShuffleInitBlock": ShuffleInitBlock}[kind]
     return ctor(**kw).eval()
 
 
