@@ -32,6 +32,7 @@ WORKLOADS = {
     "resnet18_bs256": ("resnet18", 256, "dense3x3", "mfma"),
     "mobilenetv3_large_w1_bs512": ("mobilenetv3_large_w1", 512, "depthwise", "hbm"),
     "efficientnet_b0_bs256": ("efficientnet_b0", 256, "depthwise", "hbm"),
+    "vgg16_bs128": ("vgg16", 128, "dense3x3", "mfma"),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"

@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'shufflenetv2_forward', 'shuffle_unit', 'channel_shuffle', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'shufflenetv2_forward', 'vgg_forward', 'shuffle_unit', 'channel_shuffle', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
 
 import math
 import torch
@@ -553,6 +553,24 @@ def shufflenetv2_forward(sd, x, q=None, taps=None):
     return _classifier(sd, x, q)
 
 
+def vgg_forward(sd, x, blocks=11, use_bn=False, q=None, taps=None):
+    """VGG.forward, pytorchcv/models/vgg.py:80-145: per stage conv3x3_block(bias, [BN], ReLU) x n -> MaxPool2d(2, 2);
+    view(N, -1) in NCHW order -> VGGOutputBlock (vgg.py:45-77): fc1 + ReLU -> fc2 + ReLU -> fc3 (Dropout = identity in eval).
+    The 16-bit pipeline rounds each stored activation and the weights; logits stay fp32."""
+    q = q or Quant(None)
+    layers = {11: [1, 1, 2, 2, 2], 13: [2, 2, 2, 2, 2], 16: [2, 2, 3, 3, 3], 19: [2, 2, 4, 4, 4]}[blocks]   # vgg.py:164-173
+    x = q.r(x)
+    for i, n in enumerate(layers):
+        for j in range(n):
+            x = conv_block(sd, "features.stage{}.unit{}.".format(i + 1, j + 1), x, padding=1, q=q, normalize=use_bn)
+        x = F.max_pool2d(x, kernel_size=2, stride=2, padding=0)
+        _tap(taps, "stage{}".format(i + 1), x)
+    x = x.reshape(x.size(0), -1)
+    for name in ("fc1.fc", "fc2.fc"):
+        x = q.r(F.relu(F.linear(x, q.r(sd["output." + name + ".weight"].float()), sd["output." + name + ".bias"].float())))
+    return F.linear(x, q.r(sd["output.fc3.weight"].float()), sd["output.fc3.bias"].float())
+
+
 def tf_same_pad(h, w, kernel_size, stride=1, dilation=1):
     """calc_tf_padding, efficientnet.py:27-55. Returned in F.pad order: the reference hands (pad_h//2, pad_h - pad_h//2,
     pad_w//2, pad_w - pad_w//2) to F.pad, which reads it as (left, right, top, bottom)."""
@@ -663,6 +681,10 @@ for _n, _kw in {"preresnet10": dict(blocks=10), "preresnet12": dict(blocks=12), 
         MODEL_ARCH["se" + _n] = ("preresnet", _kw)          # SE-PreResNet: same trunk, `se.` blocks in the state_dict
 for _n in ("shufflenetv2_wd2", "shufflenetv2_w1", "shufflenetv2_w3d2", "shufflenetv2_w2"):
     MODEL_ARCH[_n] = ("shufflenetv2", dict())
+for _b in (11, 13, 16, 19):
+    MODEL_ARCH["vgg{}".format(_b)] = ("vgg", dict(blocks=_b))
+    MODEL_ARCH["bn_vgg{}".format(_b)] = ("vgg", dict(blocks=_b, use_bn=True))
+    MODEL_ARCH["bn_vgg{}b".format(_b)] = ("vgg", dict(blocks=_b, use_bn=True))
 for _n in ("densenet121", "densenet161", "densenet169", "densenet201"):
     MODEL_ARCH[_n] = ("densenet", dict())
 for _v in ("b0", "b1", "b2", "b3", "b4", "b5", "b6", "b7", "b8"):
@@ -675,7 +697,7 @@ _FAMILY = {"resnet": resnet_forward, "mobilenetv2": mobilenetv2_forward, "resnex
            "seresnet": seresnet_forward, "seresnext": seresnext_forward, "mobilenet": mobilenet_forward,
            "mobilenetv3": mobilenetv3_forward, "efficientnet": efficientnet_forward,
            "preresnet": preresnet_forward, "densenet": densenet_forward,
-           "shufflenetv2": shufflenetv2_forward}
+           "shufflenetv2": shufflenetv2_forward, "vgg": vgg_forward}
 
 
 def forward(model_name: str, sd: dict, x: torch.Tensor, quant: str | None = None, taps: dict | None = None):

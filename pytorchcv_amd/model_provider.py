@@ -19,9 +19,10 @@ from .models import preresnet as _preresnet
 from .models import sepreresnet as _sepreresnet
 from .models import densenet as _densenet
 from .models import shufflenetv2 as _shufflenetv2
+from .models import vgg as _vgg
 
 _models = {}
-for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet, _mobilenetv3, _efficientnet, _preresnet, _sepreresnet, _densenet, _shufflenetv2):
+for _mod in (_resnet, _mobilenetv2, _resnext, _seresnet, _seresnext, _mobilenet, _mobilenetv3, _efficientnet, _preresnet, _sepreresnet, _densenet, _shufflenetv2, _vgg):
     for _name in _mod.__all__:
         _fn = getattr(_mod, _name)
         if _name.islower() and not _name.startswith(("get_", "calc_")) and callable(_fn):

@@ -88,14 +88,15 @@ def check_channels(net: nn.Module):
     net._pcv_channels_ok = True
 
 
-def run_net(net: nn.Module, x, head):
-    """Whole-net forward: NCHW fp32 in -> NHWC hot path -> fp32 logits [N, num_classes] out."""
+def run_net(net: nn.Module, x, head, stem: bool = True):
+    """Whole-net forward: NCHW fp32 in -> NHWC hot path -> fp32 logits [N, num_classes] out. `stem`: the first convolution
+    has stride 2 and takes the image in the 4-channel-padded stem layout (engine.from_nchw)."""
     check_channels(net)
     if isinstance(x, engine.NHWC):
         return head(net.features(x))
     if not torch.is_tensor(x) or x.dim() != 4:
         raise TypeError("expected an NCHW tensor")
-    a = engine.from_nchw(x, engine.compute_dtype_of(net), stem=True)
+    a = engine.from_nchw(x, engine.compute_dtype_of(net), stem=stem)
     return head(net.features(a))
 
 

@@ -99,7 +99,8 @@ def make_model(ref_models, name):
            "resnext101_32x4d": "resnext", "seresnet50": "seresnet", "seresnext50_32x4d": "seresnext",
            "mobilenet_w1": "mobilenet", "mobilenetv3_large_w1": "mobilenetv3", "mobilenetv3_small_w1": "mobilenetv3",
            "efficientnet_b0": "efficientnet", "efficientnet_b0b": "efficientnet",
-           "preresnet18": "preresnet", "preresnet50": "preresnet", "sepreresnet18": "sepreresnet", "densenet121": "densenet", "shufflenetv2_w1": "shufflenetv2"}[name]
+           "preresnet18": "preresnet", "preresnet50": "preresnet", "sepreresnet18": "sepreresnet", "densenet121": "densenet", "shufflenetv2_w1": "shufflenetv2",
+           "vgg11": "vgg", "bn_vgg11b": "vgg"}[name]
     m = __import__("pytorchcv.models." + mod, fromlist=[name])
     return getattr(m, name)(pretrained=False).eval()
 

@@ -18,6 +18,7 @@ _NETS = [
     ("resnext50_32x4d", 224, True), ("resnext101_64x4d", 224, False), ("seresnet18", 224, True), ("seresnext101_32x4d", 224, False),
     ("preresnet34", 224, True), ("preresnetbc26b", 224, True), ("preresnet269b", 224, False), ("sepreresnet50b", 224, True),
     ("densenet169", 224, True), ("densenet161", 224, False),
+    ("vgg16", 224, True), ("bn_vgg19", 224, False),
 ]
 
 
