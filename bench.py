@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/debug only)")
     ap.add_argument("--graph", type=int, default=-1, help="replay the forward from a captured hipGraph (1), eager launches (0), "
                                                           "default: graph")
+    ap.add_argument("--lanes", type=int, default=0, help="independent batch slices captured as parallel graph branches, so that "
+                                                        "one slice's tile-schedule tails are filled by the other's kernels "
+                                                        "(0: pytorchcv_amd.graph.auto_lanes, i.e. 2 from batch 64 up)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,7 +196,7 @@ def main():
     if use_graph:
         from pytorchcv_amd.graph import capture
         try:
-            fwd = capture(net, x, own_input=True)    # ~60 kernel launches replayed by one hipGraphLaunch; x is the static input
+            fwd = capture(net, x, own_input=True, lanes=args.lanes if args.lanes > 0 else None)    # ~60 kernel launches replayed by one hipGraphLaunch; x is the static input
         except Exception as e:                       # noqa: BLE001 - same kernels either way; only the launch mechanism differs
             print("hipGraph capture failed ({}); falling back to eager launches".format(e), file=sys.stderr)
             use_graph = False
@@ -285,7 +288,7 @@ def main():
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
             "config": {"workload": args.workload, "model": model, "per_gpu_batch": batch, "global_batch": world * batch,
                        "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world),
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": ("hipGraph replay, {} batch lane(s) as parallel branches".format(fwd.lanes) if use_graph else "eager")},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

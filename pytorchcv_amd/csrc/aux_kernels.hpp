@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in
 #pragma unroll
                     for (int i = 0; i < IMG; ++i) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(&sin[i][k]);
-                        acc[i] += wv[0] * v[0] + wv[1] * v[1] + wv[2] * v[2] + wv[3] * v[3];
+                        // explicit fma chain: every image slot must round identically (the compiler packs slot pairs into
+                        // v_pk_* ops; with `a*b + c*d + ...` some pairs got fused and others mul+add: 1-ulp batch-position dependence)
+                        acc[i] = fmaf(wv[3], v[3], fmaf(wv[2], v[2], fmaf(wv[1], v[1], fmaf(wv[0], v[0], acc[i]))));
                     }
                 }
             } else {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in
                 for (int k = kb; k < ke; ++k) {
                     const float wv = wr[k];
 #pragma unroll
-                    for (int i = 0; i < IMG; ++i) acc[i] += wv * sin[i][k];
+                    for (int i = 0; i < IMG; ++i) acc[i] = fmaf(wv, sin[i][k], acc[i]);
                 }
             }
         }

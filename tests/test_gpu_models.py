@@ -133,3 +133,21 @@ def test_graph_replay_equals_eager(cuda_device):
     assert torch.equal(y2_graph, torch.flip(y_graph, dims=[0]))
     with pytest.raises(RuntimeError, match="captured for input shape"):
         g(x[:2])
+
+
+@pytest.mark.parametrize("model,lanes", [("resnet50", 2), ("mobilenetv2_w1", 3), ("seresnet50", 2), ("densenet121", 2)])
+def test_graph_batch_lanes_equal_single_lane(model, lanes, cuda_device):
+    """The batch cut into independent graph branches (the kernels of one slice fill the tile-schedule tails of the other's):
+    same logits, bit for bit, as the one-branch graph and as eager - also when the batch does not divide evenly."""
+    from pytorchcv_amd.graph import capture
+    net = _net(model, "bf16", cuda_device)
+    x = util.synth_input(7, seed=21).to(cuda_device)
+    with torch.no_grad():
+        y_eager = net(x).clone()
+        g = capture(net, x, lanes=lanes)
+        assert g.lanes == lanes
+        y_lanes = g(x, clone=True)
+        y_again = g(torch.flip(x, dims=[0]), clone=True)
+    assert y_lanes.shape == y_eager.shape
+    assert torch.equal(y_lanes, y_eager)
+    assert torch.equal(y_again, torch.flip(y_eager, dims=[0]))
