@@ -135,7 +135,7 @@ def test_graph_replay_equals_eager(cuda_device):
         g(x[:2])
 
 
-@pytest.mark.parametrize("model,lanes", [("resnet50", 2), ("mobilenetv2_w1", 3), ("seresnet50", 2), ("densenet121", 2)])
+@pytest.mark.parametrize("model,lanes", [(m, 3 if m == "mobilenetv2_w1" else 2) for m in util.MODELS])
 def test_graph_batch_lanes_equal_single_lane(model, lanes, cuda_device):
     """The batch cut into independent graph branches (the kernels of one slice fill the tile-schedule tails of the other's):
     same logits, bit for bit, as the one-branch graph and as eager - also when the batch does not divide evenly."""
