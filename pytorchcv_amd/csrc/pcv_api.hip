@@ -13,6 +13,7 @@
 #include "hconv3x3_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
+#include "wpair1x1.hpp"
 #include "mbconv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
@@ -370,6 +371,7 @@ static int enable_stem(pcv_ctx* ctx) {
 
 static int pair_lds(int pb) { return 3 * 16 * pb * 64 * 2 + 16 * 1024 * pb; }      // x ring + reduction buffer
 static int g_pair_blocks_per_cu[2] = {1, 1};                                        // [PB == 4, PB == 2]
+static int g_wpair_blocks_per_cu = 1;                                               // wpair1x1_kernel<*, 128>
 static int enable_pair(pcv_ctx* ctx) {
     const void* fns[4] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 4>),
                           reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 4>),
@@ -381,6 +383,14 @@ static int enable_pair(pcv_ctx* ctx) {
         int nb = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, lds));
         g_pair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
+    }
+    const void* wide[2] = {reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 128>),
+                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 128>)};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, WPairCfg<128>::LDS));
+        int nb = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide[i], 256, WPairCfg<128>::LDS));
+        g_wpair_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     return PCV_OK;
 }
@@ -395,9 +405,11 @@ static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc&
     if (!plain1x1(a) || !plain1x1(b)) return "both convolutions must be plain 1x1 stride 1";
     if (a.dtype != b.dtype || (a.dtype != PCV_BF16 && a.dtype != PCV_F16)) return "16-bit storage only";
     if (a.N != b.N || a.H != b.H || a.W != b.W || a.Cout != b.Cin) return "shapes do not chain";
-    if (a.Cin != 64 || a.Cout != 256 || b.Cout != 64) return "only 64 -> 256 -> 64 is instantiated";
+    const bool narrow = a.Cin == 64 && a.Cout == 256 && b.Cout == 64;        // pair1x1.hpp: weights in registers
+    const bool wide = a.Cin == 128 && a.Cout == 512 && b.Cout == 128;        // wpair1x1.hpp: weights through an LDS ring
+    if (!narrow && !wide) return "only 64 -> 256 -> 64 and 128 -> 512 -> 128 are instantiated";
     if (!a.has_residual || b.has_residual || b.post_act != PCV_ACT_NONE) return "first conv must carry the residual, second must not";
-    if ((long)a.N * a.H * a.W * 256 * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
+    if ((long)a.N * a.H * a.W * a.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
     return nullptr;
 }
 
@@ -1112,11 +1124,32 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     const char* why = plan_conv(*d1, P1, false);
     if (!why) why = plan_conv(*d2, P2, false);
     if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_fused: ") + why);
+    const long M = (long)d1->N * d1->H * d1->W;
+    hipStream_t st = (hipStream_t)stream;
+    if (d1->Cin == 128) {
+        constexpr int CM = 128, C1 = 512;
+        if (P1.wrows != C1 || P1.Kpad != CM || P2.wrows != CM || P2.Kpad != C1 || P1.ngb != 1 || P2.ngb != 1)
+            return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
+        WPairParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.res = residual; q.y1 = y1; q.y2 = y2;
+        q.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
+        q.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
+        q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
+        q.x_bytes = q.y2_bytes = (uint32_t)(M * CM * 2); q.res_bytes = q.y1_bytes = (uint32_t)(M * C1 * 2);
+        q.w1_bytes = q.w2_bytes = C1 * CM * 2;
+        q.M = (int)M; q.nTiles = (int)((M + WPairCfg<CM>::P - 1) / WPairCfg<CM>::P);
+        q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
+        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu);
+        if (d1->dtype == PCV_BF16) wpair1x1_kernel<PCV_BF16, CM><<<grid, 256, WPairCfg<CM>::LDS, st>>>(q);
+        else wpair1x1_kernel<PCV_F16, CM><<<grid, 256, WPairCfg<CM>::LDS, st>>>(q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
     if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || P1.ngb != 1 || P2.ngb != 1)
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
     PairParams p;
     std::memset(&p, 0, sizeof(p));
-    const long M = (long)d1->N * d1->H * d1->W;
     p.x = x; p.res = residual; p.y1 = y1; p.y2 = y2;
     p.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
     p.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
@@ -1127,7 +1160,6 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     p.M = (int)M; p.nTiles = (int)((M + 16 * pb - 1) / (16 * pb));
     p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
     const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_blocks_per_cu[pb == 4 ? 0 : 1]);
-    hipStream_t st = (hipStream_t)stream;
     if (pb == 4) {
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 4><<<grid, 256, pair_lds(4), st>>>(p);
         else pair1x1_kernel<PCV_F16, 4><<<grid, 256, pair_lds(4), st>>>(p);
