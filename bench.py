@@ -176,6 +176,10 @@ def main():
     from pytorchcv_amd.synth import synth_state_dict, synth_input
     from pytorchcv_amd.parallel import ShardedInference, broadcast_module_state
 
+    for kv in filter(None, os.environ.get("PCV_BENCH_TUNE", "").split(",")):       # dev only: "key=value,..." -> pcv_set_tuning
+        from pytorchcv_amd import _lib
+        k, v = kv.split("=")
+        _lib.check(_lib.lib().pcv_set_tuning(_lib.ctx_for(local_rank), k.encode(), int(v)), _lib.ctx_for(local_rank))
     model, batch, klass, bound = WORKLOADS[args.workload]
     if args.batch > 0:
         batch = args.batch

@@ -371,7 +371,8 @@ static int enable_stem(pcv_ctx* ctx) {
 
 static int pair_lds(int pb) { return 3 * 16 * pb * 64 * 2 + 16 * 1024 * pb; }      // x ring + reduction buffer
 static int g_pair_blocks_per_cu[2] = {1, 1};                                        // [PB == 4, PB == 2]
-static int g_wpair_blocks_per_cu = 1;                                               // wpair1x1_kernel<*, 128>
+static int g_wpair_mask = 3;                                                        // bit 0: CM = 128, bit 1: CM = 256 (tuning)
+static int g_wpair_blocks_per_cu[2] = {1, 1};                                       // wpair1x1_kernel<*, 128 | 256>
 static int enable_pair(pcv_ctx* ctx) {
     const void* fns[4] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 4>),
                           reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 4>),
@@ -384,13 +385,16 @@ static int enable_pair(pcv_ctx* ctx) {
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, lds));
         g_pair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
     }
-    const void* wide[2] = {reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 128>),
-                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 128>)};
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(ctx, hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, WPairCfg<128>::LDS));
+    const void* wide[4] = {reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 128>),
+                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 128>),
+                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 256>),
+                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 256>)};
+    for (int i = 0; i < 4; ++i) {
+        const int lds = i < 2 ? WPairCfg<128>::LDS : WPairCfg<256>::LDS;
+        HIP_TRY(ctx, hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         int nb = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide[i], 256, WPairCfg<128>::LDS));
-        g_wpair_blocks_per_cu = nb < 1 ? 1 : nb;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide[i], i < 2 ? 64 * WPairCfg<128>::NW : 64 * WPairCfg<256>::NW, lds));
+        g_wpair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
     }
     return PCV_OK;
 }
@@ -406,8 +410,9 @@ static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc&
     if (a.dtype != b.dtype || (a.dtype != PCV_BF16 && a.dtype != PCV_F16)) return "16-bit storage only";
     if (a.N != b.N || a.H != b.H || a.W != b.W || a.Cout != b.Cin) return "shapes do not chain";
     const bool narrow = a.Cin == 64 && a.Cout == 256 && b.Cout == 64;        // pair1x1.hpp: weights in registers
-    const bool wide = a.Cin == 128 && a.Cout == 512 && b.Cout == 128;        // wpair1x1.hpp: weights through an LDS ring
-    if (!narrow && !wide) return "only 64 -> 256 -> 64 and 128 -> 512 -> 128 are instantiated";
+    const bool wide = ((a.Cin == 128 && (g_wpair_mask & 1)) || (a.Cin == 256 && (g_wpair_mask & 2))) && a.Cout == 4 * a.Cin &&
+                      b.Cout == a.Cin;   // wpair1x1.hpp: weights through an LDS ring
+    if (!narrow && !wide) return "only 64 -> 256 -> 64, 128 -> 512 -> 128 and 256 -> 1024 -> 256 are instantiated";
     if (!a.has_residual || b.has_residual || b.post_act != PCV_ACT_NONE) return "first conv must carry the residual, second must not";
     if ((long)a.N * a.H * a.W * a.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
     return nullptr;
@@ -569,6 +574,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "c3flags") ctx->conv3_flags = value;
     else if (k == "tile") ctx->force_tile = value;
     else if (k == "pair_pb") ctx->pair_pb = value;
+    else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "hconv") ctx->use_hconv = value;
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
@@ -1126,8 +1132,8 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_fused: ") + why);
     const long M = (long)d1->N * d1->H * d1->W;
     hipStream_t st = (hipStream_t)stream;
-    if (d1->Cin == 128) {
-        constexpr int CM = 128, C1 = 512;
+    if (d1->Cin >= 128) {
+        const int CM = d1->Cin, C1 = 4 * CM;
         if (P1.wrows != C1 || P1.Kpad != CM || P2.wrows != CM || P2.Kpad != C1 || P1.ngb != 1 || P2.ngb != 1)
             return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
         WPairParams q;
@@ -1137,12 +1143,19 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         q.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
         q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
         q.x_bytes = q.y2_bytes = (uint32_t)(M * CM * 2); q.res_bytes = q.y1_bytes = (uint32_t)(M * C1 * 2);
-        q.w1_bytes = q.w2_bytes = C1 * CM * 2;
-        q.M = (int)M; q.nTiles = (int)((M + WPairCfg<CM>::P - 1) / WPairCfg<CM>::P);
+        q.w1_bytes = q.w2_bytes = (uint32_t)(C1 * CM * 2);
+        const int tileP = CM == 128 ? WPairCfg<128>::P : WPairCfg<256>::P;
+        q.M = (int)M; q.nTiles = (int)((M + tileP - 1) / tileP);
         q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
-        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu);
-        if (d1->dtype == PCV_BF16) wpair1x1_kernel<PCV_BF16, CM><<<grid, 256, WPairCfg<CM>::LDS, st>>>(q);
-        else wpair1x1_kernel<PCV_F16, CM><<<grid, 256, WPairCfg<CM>::LDS, st>>>(q);
+        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[CM == 128 ? 0 : 1]);
+        const bool bf = d1->dtype == PCV_BF16;
+        if (CM == 128) {
+            if (bf) wpair1x1_kernel<PCV_BF16, 128><<<grid, 256, WPairCfg<128>::LDS, st>>>(q);
+            else wpair1x1_kernel<PCV_F16, 128><<<grid, 256, WPairCfg<128>::LDS, st>>>(q);
+        } else {
+            if (bf) wpair1x1_kernel<PCV_BF16, 256><<<grid, 64 * WPairCfg<256>::NW, WPairCfg<256>::LDS, st>>>(q);
+            else wpair1x1_kernel<PCV_F16, 256><<<grid, 64 * WPairCfg<256>::NW, WPairCfg<256>::LDS, st>>>(q);
+        }
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }

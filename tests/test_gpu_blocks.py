@@ -160,8 +160,8 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("cm", [64, 128])
-@pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 8, 8), (5, 28, 28)])
+@pytest.mark.parametrize("cm", [64, 128, 256])
+@pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 8, 8), (5, 28, 28), (9, 14, 14)])
 def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     """pcv_conv1x1_pair_fused (unit's last 1x1 + skip add + ReLU, then the next unit's first 1x1) against the same two
     ConvBlocks run as separate launches; pixel counts that are not a multiple of the 64-pixel tile included."""
@@ -185,12 +185,12 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
         y1_ref = first(x, residual=r, post_act=relu)
         y2_ref = second(y1_ref)
         pair = conv_block_pair(first, x, r, relu, second)
-    assert pair is not None, "the 64 -> 256 -> 64 and 128 -> 512 -> 128 pairs must be covered by the fused kernels"
+    assert pair is not None, "the 64 -> 256 -> 64, 128 -> 512 -> 128 and 256 -> 1024 -> 256 pairs must be covered by the fused kernels"
     torch.cuda.synchronize()
     y1, y2 = pair
     assert y1.t.shape == y1_ref.t.shape and y2.t.shape == y2_ref.t.shape
     assert torch.equal(y1.t, y1_ref.t)                       # same accumulation order and epilogue arithmetic
-    if cm == 128:
+    if cm >= 128:
         assert torch.equal(y2.t, y2_ref.t)                   # the wide kernel keeps a pixel's whole K sum in one wave, in order
         return
     d2 = float((y2.t.float() - y2_ref.t.float()).abs().max())
@@ -203,10 +203,10 @@ def test_conv1x1_pair_unsupported_shapes_fall_back(cuda_device):
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv1x1_block, conv_block_pair
-    first = pytorchcv_amd.set_compute_dtype(conv1x1_block(in_channels=256, out_channels=1024, activation=None).eval().to(cuda_device), "bf16")
-    second = pytorchcv_amd.set_compute_dtype(conv1x1_block(in_channels=1024, out_channels=256).eval().to(cuda_device), "bf16")
-    x = engine.NHWC(torch.zeros((1, 4, 4, 256), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 256)
-    r = engine.NHWC(torch.zeros((1, 4, 4, 1024), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 1024)
+    first = pytorchcv_amd.set_compute_dtype(conv1x1_block(in_channels=512, out_channels=2048, activation=None).eval().to(cuda_device), "bf16")
+    second = pytorchcv_amd.set_compute_dtype(conv1x1_block(in_channels=2048, out_channels=512).eval().to(cuda_device), "bf16")
+    x = engine.NHWC(torch.zeros((1, 4, 4, 512), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 512)
+    r = engine.NHWC(torch.zeros((1, 4, 4, 2048), dtype=torch.bfloat16, device=cuda_device), 1, 4, 4, 2048)
     assert conv_block_pair(first, x, r, nn.ReLU(), second) is None
 
 
