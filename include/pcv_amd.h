@@ -164,6 +164,16 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
                            const void* packed1, const float* scale1, const float* shift1, const void* residual, void* y1,
                            const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
 
+/* The same pair when the unit's skip tensor is itself a 1x1 convolution + BN of the unit's input x0 (first unit of a stage,
+ * `identity_conv`, resnet.py:214-216,225-226): the kernel recomputes the skip tile from x0 instead of reading it, so the
+ * identity convolution's own launch and both passes over its 4x wider output disappear. `d_id` describes the identity
+ * convolution (x0 -> skip, no activation, stride 1), d1/d2 as above with d1->has_residual = 1. Covered today: 64 -> 256 pairs. */
+int pcv_conv1x1_pair_idconv_supported(const pcv_conv_desc* d_id, const pcv_conv_desc* d1, const pcv_conv_desc* d2);
+int pcv_conv1x1_pair_idconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_id, const pcv_conv_desc* d1, const pcv_conv_desc* d2,
+                                  const void* x0, const void* packed_id, const float* scale_id, const float* shift_id,
+                                  const void* x, const void* packed1, const float* scale1, const float* shift1, void* y1,
+                                  const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
+
 /* A whole inverted-residual unit in one launch: [1x1 expand ConvBlock] -> depthwise 3x3 ConvBlock -> 1x1 project ConvBlock
  * (+ skip add): LinearBottleneck.forward (mobilenetv2.py:62-71), MobileNetV3Unit without SE (mobilenetv3.py:82-93),
  * DwsConvBlock (conv.py:612-615; d_exp == NULL). The expanded tensor stays on the CU. The descriptors and packed blobs are

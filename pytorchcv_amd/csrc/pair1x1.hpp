@@ -17,6 +17,12 @@
 // All weights live in registers for the whole persistent block; LDS holds a 3-deep ring of x tiles (8 KB each,
 // LDS-DMA with the source-side XOR swizzle) and the 64 KB reduction buffer: one block per CU with the full 512-register
 // budget, so latency is hidden by software prefetch: x and the residual two tiles ahead.
+//
+// IDC variant (first unit of the stage, reference resnet.py:214-228 with resize_identity): the skip tensor is itself a 1x1
+// convolution + BN of the unit's input x0 (64 -> 256, no activation). Instead of reading its 256-channel result the block
+// recomputes it from the 64-channel x0 tile (a third register-resident weight slice, 16 more MFMA per wave per tile), rounds it
+// to the storage type exactly where the separate launch would have stored it, and adds it: the identity convolution's
+// launch, its 411 MB write and the 411 MB residual read of this kernel all disappear (at 56x56, batch 256).
 #pragma once
 #include "pcv_common.hpp"
 #include <type_traits>
@@ -36,6 +42,12 @@ struct PairParams {
     uint32_t x_bytes, res_bytes, y1_bytes, y2_bytes, w1_bytes, w2_bytes;
     int M, nTiles;
     int act1, post1, act2;
+    // IDC: skip = BN_id(W_id . x0) instead of `res`
+    const void* x0;           // [M][64]
+    const void* wid;          // packed rows [256][64]
+    const float* scale_id;
+    const float* shift_id;
+    uint32_t x0_bytes, wid_bytes;
 };
 
 template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
@@ -44,7 +56,7 @@ template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
 
 // PB: 16-pixel blocks per tile. PB = 4: 64-pixel tiles, one block per CU (needs > 256 registers); PB = 2: 32-pixel tiles,
 // half the accumulators, fits 256 registers and 44 KB of LDS -> two blocks (8 waves) per CU, which hides HBM latency better.
-template <int DT, int PB>
+template <int DT, int PB, bool IDC = false>
 __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const PairParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int K1 = 64, C1 = 256, C2 = 64, P = 16 * PB;
@@ -52,8 +64,9 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
     constexpr int NIP = PB / 2;                                   // 32-channel output groups finished per wave
     constexpr int XB = P * K1 * 2;                                // bytes per x tile
     typedef typename Mma<DT>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [x ring: 3 tiles | reduction: 16 KB x PB]
-    char* const red = smem + 3 * XB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [x ring: 3 tiles | (IDC: x0 ring: 3 tiles) | reduction: 16 KB x PB]
+    char* const x0ring = smem + 3 * XB;
+    char* const red = smem + (IDC ? 6 : 3) * XB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -70,6 +83,8 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
     const __amdgpu_buffer_rsrc_t y2rsrc = __builtin_amdgcn_make_buffer_rsrc(p.y2, 0, p.y2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, p.w1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, p.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x0rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IDC ? p.x0 : p.x), 0, IDC ? p.x0_bytes : p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t widrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IDC ? p.wid : p.w1), 0, IDC ? p.wid_bytes : p.w1_bytes, 0x00020000);
 
     // ---- weights -> registers (once) -----------------------------------------------------------------------------
     frag a1[4][2];      // W1 rows 64w + 16i + fr, K-step ks
@@ -85,15 +100,36 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
             a1[i][ks] = __builtin_bit_cast(frag, v1);
             a2[i][ks] = __builtin_bit_cast(frag, v2);
         }
+    frag aid[IDC ? 4 : 1][2];                                  // IDC: W_id rows 64w + 16i + fr
+    if constexpr (IDC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                aid[i][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(
+                    widrsrc, (uint32_t)(((64 * wave + 16 * i + fr) * K1 + ks * 32 + 8 * fq) * 2), 0, 0));
+    }
     // epilogue constants: channels 64w + 32ip + 8fq + e (first GEMM), 32ip + 8fq + e (second GEMM)
     float sc1[2][8], sf1[2][8], sc2[NIP][8], sf2[NIP][8];
+    // IDC: the identity convolution's BN constants live in LDS (2 KB behind the reduction buffer; the registers are full)
+    float* const tscid = reinterpret_cast<float*>(red + 16 * 1024 * PB);
+    float* const tsfid = tscid + C1;
+    float* const tsc1 = tsfid + C1;                             // IDC: the first convolution's constants too (4 KB in all)
+    float* const tsf1 = tsc1 + C1;
+    if constexpr (IDC) {
+        for (int i = tid; i < C1; i += 256) {
+            tscid[i] = p.scale_id[i]; tsfid[i] = p.shift_id[i];
+            tsc1[i] = p.scale1[i]; tsf1[i] = p.shift1[i];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c1 = 64 * wave + 32 * ip + 8 * fq + e;
-            sc1[ip][e] = p.scale1[c1];
-            sf1[ip][e] = p.shift1[c1];
+            sc1[ip][e] = IDC ? 0.f : p.scale1[c1];
+            sf1[ip][e] = IDC ? 0.f : p.shift1[c1];
         }
 #pragma unroll
     for (int k = 0; k < NIP; ++k)
@@ -121,6 +157,8 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
             const long pix = (long)t * P + xrow[q];
             const uint32_t off = (t < p.nTiles && pix < p.M) ? (uint32_t)((pix * K1 + xchunk[q] * 8) * 2) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(smem + slot * XB + (NXQ * wave + q) * 1024), 16, off, 0, 0, 0);
+            if constexpr (IDC)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x0rsrc, PCV_LDS(x0ring + slot * XB + (NXQ * wave + q) * 1024), 16, off, 0, 0, 0);
         }
     };
     // residual / y1 element (ip, j): pixel 16j + fr, channels 64w + 32ip + 8fq .. +8
@@ -129,6 +167,7 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
         return (t < p.nTiles && pix < p.M) ? (uint32_t)((pix * C1 + 64 * wave + 32 * ip + 8 * fq) * 2) : 0x80000000u;
     };
     auto load_res = [&](int t, u32x4 (&r)[2][PB]) {
+        if constexpr (IDC) return;                              // the skip tensor is computed, not read
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -162,9 +201,45 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
         u32x4 (&resc)[2][PB] = resr[slot];
         // x(t) landed: all but the 5 PB youngest VMEM ops of this wave are done - those are the previous iteration's
         // x(t+2) [PB/2], residual(t+2) [2 PB], y1 stores [2 PB], y2 stores [PB/2] (always issued, out of range when invalid).
-        if (!first) pair_wait_vmcnt<5 * PB>();
+        // IDC: x(t+2) + x0(t+2) [PB], no residual loads, y1 stores [2 PB], y2 stores [PB/2].
+        if (!first) pair_wait_vmcnt<IDC ? (7 * PB) / 2 : 5 * PB>();
         first = false;
         __syncthreads();
+
+        // ---- IDC: the skip tensor of this tile = round(BN_id(W_id . x0)), kept as the packed residual ---------------------
+        if constexpr (IDC) {
+            f32x4 accd[4][PB];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < PB; ++j) accd[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const char* x0b = x0ring + slot * XB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                frag b[PB];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) b[j] = *reinterpret_cast<const frag*>(x0b + xfrag[j][ks]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) accd[i][j] = Mma<DT>::run(aid[i][ks], b[j], accd[i][j]);
+            }
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const int ch = 64 * wave + 32 * ip + 8 * fq;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(tscid + ch), s1 = *reinterpret_cast<const f32x4*>(tscid + ch + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(tsfid + ch), h1 = *reinterpret_cast<const f32x4*>(tsfid + ch + 4);
+#pragma unroll
+                for (int j = 0; j < PB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        resc[ip][j][e] = pack2<DT>(accd[2 * ip][j][2 * e] * s0[2 * e] + h0[2 * e],
+                                                   accd[2 * ip][j][2 * e + 1] * s0[2 * e + 1] + h0[2 * e + 1]);
+                        resc[ip][j][2 + e] = pack2<DT>(accd[2 * ip + 1][j][2 * e] * s1[2 * e] + h1[2 * e],
+                                                       accd[2 * ip + 1][j][2 * e + 1] * s1[2 * e + 1] + h1[2 * e + 1]);
+                    }
+            }
+        }
 
         // ---- GEMM1 ----------------------------------------------------------------------------------------------------
         f32x4 acc[4][PB];
@@ -195,10 +270,21 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
 #pragma unroll
             for (int j = 0; j < PB; ++j) {
                 float v[8], r8[8];
+                if constexpr (IDC) {
+                    const int ch = 64 * wave + 32 * ip + 8 * fq;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(tsc1 + ch), s1 = *reinterpret_cast<const f32x4*>(tsc1 + ch + 4);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(tsf1 + ch), h1 = *reinterpret_cast<const f32x4*>(tsf1 + ch + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[2 * ip][j][e] * sc1[ip][e] + sf1[ip][e];
-                    v[4 + e] = acc[2 * ip + 1][j][e] * sc1[ip][4 + e] + sf1[ip][4 + e];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[2 * ip][j][e] * s0[e] + h0[e];
+                        v[4 + e] = acc[2 * ip + 1][j][e] * s1[e] + h1[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[2 * ip][j][e] * sc1[ip][e] + sf1[ip][e];
+                        v[4 + e] = acc[2 * ip + 1][j][e] * sc1[ip][4 + e] + sf1[ip][4 + e];
+                    }
                 }
                 apply_act8(v, act1);
 #pragma unroll

@@ -369,7 +369,8 @@ static int enable_stem(pcv_ctx* ctx) {
     return PCV_OK;
 }
 
-static int pair_lds(int pb) { return 3 * 16 * pb * 64 * 2 + 16 * 1024 * pb; }      // x ring + reduction buffer
+static int pair_lds(int pb, bool idc = false) { return (idc ? 6 : 3) * 16 * pb * 64 * 2 + 16 * 1024 * pb + (idc ? 4096 : 0); }   // x (+ x0) ring + reduction buffer
+static int g_pair_idc_blocks_per_cu = 1;
 static int g_pair_blocks_per_cu[2] = {1, 1};                                        // [PB == 4, PB == 2]
 static int g_wpair_mask = 3;                                                        // bit 0: CM = 128, bit 1: CM = 256 (tuning)
 static int g_wpair_blocks_per_cu[2] = {1, 1};                                       // wpair1x1_kernel<*, 128 | 256>
@@ -384,6 +385,14 @@ static int enable_pair(pcv_ctx* ctx) {
         int nb = 0;
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, lds));
         g_pair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
+    }
+    const void* idc[2] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 2, true>),
+                          reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 2, true>)};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipFuncSetAttribute(idc[i], hipFuncAttributeMaxDynamicSharedMemorySize, pair_lds(2, true)));
+        int nb = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, idc[i], 256, pair_lds(2, true)));
+        g_pair_idc_blocks_per_cu = nb < 1 ? 1 : nb;
     }
     const void* wide[4] = {reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 128>),
                            reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 128>),
@@ -1180,6 +1189,65 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2><<<grid, 256, pair_lds(2), st>>>(p);
         else pair1x1_kernel<PCV_F16, 2><<<grid, 256, pair_lds(2), st>>>(p);
     }
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+static const char* pair_idconv_unsupported(const pcv_conv_desc& di, const pcv_conv_desc& a, const pcv_conv_desc& b) {
+    if (const char* why = pair_unsupported(a, b)) return why;
+    if (a.Cin != 64) return "identity-convolution variant: only the 64 -> 256 -> 64 pair is instantiated";
+    const bool plain = di.kh == 1 && di.kw == 1 && di.stride_h == 1 && di.stride_w == 1 && di.pad_t == 0 && di.pad_l == 0 &&
+                       di.pad_b == 0 && di.pad_r == 0 && di.groups == 1 && di.dil_h == 1 && di.dil_w == 1 &&
+                       di.out_dtype == di.dtype && (di.x_cpitch == 0 || di.x_cpitch == di.Cin) &&
+                       (di.x_wpitch == 0 || di.x_wpitch == di.W) && (di.y_cpitch == 0 || di.y_cpitch == di.Cout);
+    if (!plain || di.dtype != a.dtype) return "identity convolution must be a plain 1x1 stride 1 of the same dtype";
+    if (di.N != a.N || di.H != a.H || di.W != a.W || di.Cin != 64 || di.Cout != a.Cout) return "identity convolution shapes do not match";
+    if (di.act != PCV_ACT_NONE || di.has_residual || di.post_act != PCV_ACT_NONE) return "identity convolution must have no activation";
+    return nullptr;
+}
+
+int pcv_conv1x1_pair_idconv_supported(const pcv_conv_desc* d_id, const pcv_conv_desc* d1, const pcv_conv_desc* d2) {
+    return (d_id && d1 && d2 && pair_idconv_unsupported(*d_id, *d1, *d2) == nullptr) ? 1 : 0;
+}
+
+int pcv_conv1x1_pair_idconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_id, const pcv_conv_desc* d1, const pcv_conv_desc* d2,
+                                  const void* x0, const void* packed_id, const float* scale_id, const float* shift_id,
+                                  const void* x, const void* packed1, const float* scale1, const float* shift1, void* y1,
+                                  const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!d_id || !d1 || !d2 || !x0 || !packed_id || !scale_id || !shift_id || !x || !packed1 || !scale1 || !shift1 || !y1 ||
+        !packed2 || !scale2 || !shift2 || !y2)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_idconv_fused: NULL argument");
+    if (const char* why = pair_idconv_unsupported(*d_id, *d1, *d2))
+        return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_idconv_fused: ") + why);
+    if (!aligned16(x0) || !aligned16(packed_id) || !aligned16(x) || !aligned16(packed1) || !aligned16(packed2) || !aligned16(y1) ||
+        !aligned16(y2))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_idconv_fused: pointers must be 16-byte aligned");
+    ConvPlan Pi, P1, P2;
+    const char* why = plan_conv(*d_id, Pi, false);
+    if (!why) why = plan_conv(*d1, P1, false);
+    if (!why) why = plan_conv(*d2, P2, false);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv1x1_pair_idconv_fused: ") + why);
+    if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || Pi.wrows != 256 || Pi.Kpad != 64 || P1.ngb != 1 ||
+        P2.ngb != 1 || Pi.ngb != 1)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_idconv_fused: unexpected packed layout");
+    PairParams p;
+    std::memset(&p, 0, sizeof(p));
+    const long M = (long)d1->N * d1->H * d1->W;
+    p.x = x; p.res = nullptr; p.y1 = y1; p.y2 = y2; p.x0 = x0;
+    p.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
+    p.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
+    p.wid = static_cast<const char*>(packed_id) + Pi.ktab_bytes;
+    p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2; p.scale_id = scale_id; p.shift_id = shift_id;
+    p.x_bytes = p.x0_bytes = (uint32_t)(M * 64 * 2); p.res_bytes = 0; p.y1_bytes = (uint32_t)(M * 256 * 2); p.y2_bytes = (uint32_t)(M * 64 * 2);
+    p.w1_bytes = p.wid_bytes = 256 * 64 * 2; p.w2_bytes = 64 * 256 * 2;
+    p.M = (int)M; p.nTiles = (int)((M + 31) / 32);
+    p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_idc_blocks_per_cu);
+    hipStream_t st = (hipStream_t)stream;
+    if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2, true><<<grid, 256, pair_lds(2, true), st>>>(p);
+    else pair1x1_kernel<PCV_F16, 2, true><<<grid, 256, pair_lds(2, true), st>>>(p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

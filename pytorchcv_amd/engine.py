@@ -304,6 +304,35 @@ class ConvRunner(object):
                                             _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
         return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels, cpitch=d2.Cout)
 
+    def run_pair_idconv(self, x: NHWC, x0: NHWC, idr: "ConvRunner", act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
+        """`run_pair` for the first unit of a stage: the skip tensor is `idr` (1x1 convolution + BN, no activation) applied to
+        the unit's input `x0`, recomputed inside the fused kernel instead of being written and read back
+        (pcv_conv1x1_pair_idconv_fused). Returns (y1, y2), or None when the shapes are not covered."""
+        if not FUSE_UNITS or any(r.depthwise or r.pad4 is not None for r in (self, idr, nxt)):
+            return None
+        if any(r.bn is not None and r.bn.training for r in (self, idr, nxt)):
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        if not x0.dense or x0.dtype != x.dtype or (x0.N, x0.H, x0.W) != (x.N, x.H, x.W):
+            return None
+        c = self.conv
+        L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
+        di = idr.desc(x0, 0, 0, False)
+        d1 = self.desc(x, act, post_act, True)
+        d2 = nxt.desc(_ShapeOnly(x.N, x.H, x.W, c.out_channels, x.dtype), nxt_act, 0, False)
+        if not L.pcv_conv1x1_pair_idconv_supported(ctypes.byref(di), ctypes.byref(d1), ctypes.byref(d2)):
+            return None
+        t1 = torch.empty((x.N, x.H, x.W, d1.Cout), dtype=x.dtype, device=x.device)
+        t2 = torch.empty((x.N, x.H, x.W, d2.Cout), dtype=x.dtype, device=x.device)
+        y1 = NHWC(t1, x.N, x.H, x.W, c.out_channels, cpitch=d1.Cout)
+        idr.prepare(x0, di)
+        self.prepare(x, d1)
+        nxt.prepare(y1, d2)
+        _lib.check(L.pcv_conv1x1_pair_idconv_fused(ctx, ctypes.byref(di), ctypes.byref(d1), ctypes.byref(d2), _ptr(x0.t),
+                                                   _ptr(idr.packed), _ptr(idr.scale), _ptr(idr.shift), _ptr(x.t), _ptr(self.packed),
+                                                   _ptr(self.scale), _ptr(self.shift), _ptr(t1), _ptr(nxt.packed), _ptr(nxt.scale),
+                                                   _ptr(nxt.shift), _ptr(t2), st), ctx)
+        return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels, cpitch=d2.Cout)
+
     def _launch(self, x: NHWC, d: ConvDesc, residual, out=None):
         """`out` = (tensor [N, Ho, Wo, Ctot], channel offset): write the result into that channel slice of a wider
         (concatenation) buffer instead of a fresh tensor - `torch.cat((identity, x), dim=1)` without the copy."""

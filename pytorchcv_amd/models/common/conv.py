@@ -78,14 +78,24 @@ class ConvBlock(nn.Module):
                                                                        pad4=pad4))
 
 
-def conv_block_pair(first, x, residual, post_act, second):
+def conv_block_pair(first, x, residual, post_act, second, id_block=None, x0=None):
     """`first` (with the unit's skip add and activation) and the ConvBlock `second` that consumes its output, as one fused
-    launch when the pair of shapes is covered (pcv_conv1x1_pair_fused): (y_first, y_second), else None."""
+    launch when the pair of shapes is covered (pcv_conv1x1_pair_fused): (y_first, y_second), else None. With `id_block`
+    (the unit's `identity_conv`, a ConvBlock without activation) and the unit input `x0` instead of `residual`, the skip
+    tensor is recomputed inside the launch (pcv_conv1x1_pair_idconv_fused)."""
     if not (isinstance(first, ConvBlock) and isinstance(second, ConvBlock) and isinstance(x, engine.NHWC)):
         return None
-    for blk in (first, second):
+    for blk in (first, second) + ((id_block,) if id_block is not None else ()):
+        if not isinstance(blk, ConvBlock):
+            return None
         if blk._pcv_runner is None:
             blk._pcv_runner = engine.ConvRunner(blk.conv, blk.bn if blk.normalize else None, pad4=blk._pad4)
+    if id_block is not None:
+        if id_block.activate or not isinstance(x0, engine.NHWC):
+            return None
+        return first._pcv_runner.run_pair_idconv(x, x0, id_block._pcv_runner, engine.act_code(first.activ) if first.activate else 0,
+                                                 engine.act_code(post_act), second._pcv_runner,
+                                                 engine.act_code(second.activ) if second.activate else 0)
     return first._pcv_runner.run_pair(x, residual, engine.act_code(first.activ) if first.activate else 0,
                                       engine.act_code(post_act), second._pcv_runner,
                                       engine.act_code(second.activ) if second.activate else 0)

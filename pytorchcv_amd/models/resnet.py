@@ -77,9 +77,14 @@ class ResUnit(nn.Module):
         already produced it; with `next_unit`, the last convolution (+ skip add + ReLU) and the next unit's first
         convolution go out as one launch whenever the pair is covered. Returns (unit output, next unit's conv1 output
         or None)."""
-        identity = self.identity_conv(a) if self.resize_identity else a
         body = self.body
         y = body.conv2(conv1_out if conv1_out is not None else body.conv1(a))
+        if next_unit is not None and self.resize_identity:
+            # the skip convolution recomputed inside the fused pair (no launch, no 4x wider tensor written and re-read)
+            pair = conv_block_pair(body.conv3, y, None, self.activ, next_unit.body.conv1, id_block=self.identity_conv, x0=a)
+            if pair is not None:
+                return pair
+        identity = self.identity_conv(a) if self.resize_identity else a
         if next_unit is not None:
             pair = conv_block_pair(body.conv3, y, identity, self.activ, next_unit.body.conv1)
             if pair is not None:

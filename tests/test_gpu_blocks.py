@@ -198,6 +198,41 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     assert d2 <= (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * scale      # K-slice summation order differs: 1 ulp
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 5, 7)])
+def test_conv1x1_pair_idconv_fused_matches_three_launches(shape, dtype, cuda_device):
+    """pcv_conv1x1_pair_idconv_fused: identity 1x1 convolution of the unit input recomputed inside the fused pair, against
+    identity conv -> conv3 (+ skip, ReLU) -> next conv1 as three launches. The skip tensor is rounded to the storage type at
+    the same point, so y1 is bit-identical."""
+    import torch.nn as nn
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block, conv_block_pair
+    N, H, W = shape
+    ident = conv1x1_block(in_channels=64, out_channels=256, activation=None).eval()
+    first = conv1x1_block(in_channels=64, out_channels=256, activation=None).eval()
+    second = conv1x1_block(in_channels=256, out_channels=64).eval()
+    for i, blk in enumerate((ident, first, second)):
+        blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=31 + i))
+    ident, first, second = [pytorchcv_amd.set_compute_dtype(b.to(cuda_device), dtype) for b in (ident, first, second)]
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(6)
+    x0 = engine.NHWC(torch.randn((N, H, W, 64), generator=g).to(cuda_device).to(tdt), N, H, W, 64)
+    x = engine.NHWC(torch.randn((N, H, W, 64), generator=g).to(cuda_device).to(tdt), N, H, W, 64)
+    relu = nn.ReLU()
+    with torch.no_grad():
+        y1_ref = first(x, residual=ident(x0), post_act=relu)
+        y2_ref = second(y1_ref)
+        pair = conv_block_pair(first, x, None, relu, second, id_block=ident, x0=x0)
+    assert pair is not None, "the 64 -> 256 identity-convolution pair must be covered by the fused kernel"
+    torch.cuda.synchronize()
+    y1, y2 = pair
+    assert torch.equal(y1.t, y1_ref.t)
+    d2 = float((y2.t.float() - y2_ref.t.float()).abs().max())
+    scale = max(1.0, float(y2_ref.t.float().abs().max()))
+    assert d2 <= (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * scale      # K-slice summation order differs: 1 ulp
+
+
 def test_conv1x1_pair_unsupported_shapes_fall_back(cuda_device):
     import torch.nn as nn
     import pytorchcv_amd
