@@ -118,6 +118,15 @@ int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, cons
  * residual (or NULL) and y NHWC [N,Ho,Wo,Cout]. */
 int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
                      const float* scale, const float* shift, const void* residual, void* y, void* stream);
+
+/* The stem convolution (Cin <= 4, stride 2, Cout <= 64, 16 bit) and the MaxPool2d(3, stride 2, pad 1) that follows it in the
+ * ResNet-style init blocks (reference resnet.py:250-258: `conv` then `pool`) as ONE launch: y is the POOLED map
+ * [N, Hq, Wq, Cout] (Hq = (Ho + 2 - 3) / 2 + 1), the full-resolution convolution output is never written. Results are
+ * bit-identical to pcv_conv2d_fused followed by pcv_maxpool2d. `pcv_conv2d_maxpool_supported` tells whether a descriptor and
+ * pooling geometry are covered (the caller otherwise issues the two launches). */
+int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, int ceil_mode);
+int pcv_conv2d_maxpool_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                             const float* shift, void* y, int k, int s, int p, int ceil_mode, void* stream);
 /* Depthwise direct convolution, fused epilogue (same contract). */
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
                        const float* scale, const float* shift, const void* residual, void* y, void* stream);

@@ -355,11 +355,14 @@ static int enable_hconv(pcv_ctx* ctx) {
 }
 
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
-static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16;
+static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16 + 3 * 2 * 64 * 16;     // weights + 2 patches + the pooled variant's row hand-down
 static int g_stem_blocks_per_cu[2];
 static int enable_stem(pcv_ctx* ctx) {
-    const void* fns[2] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16>),
-                          reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16>)};
+    const void* fns[2] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, false>),
+                          reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, false>)};
+    const void* pooled[2] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, true>),
+                             reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, true>)};
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipFuncSetAttribute(pooled[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
         int nb = 0;
@@ -738,8 +741,11 @@ int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, cons
 }
 
 // ---- hot path ----------------------------------------------------------------------------------------------
-int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
-                     const float* shift, const void* residual, void* y, void* stream) {
+static int pool_out(int in, int k, int s, int p, int ceil_mode);
+
+// pool: the MaxPool2d(3, 2, 1) of the init block fused behind the stem convolution (pcv_conv2d_maxpool_fused)
+static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                       const float* shift, const void* residual, void* y, void* stream, bool pool) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
     if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
@@ -763,17 +769,21 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
 
     const bool sliced_y = d->y_cpitch > 0 && d->y_cpitch != d->Cout;
     if (P.stem && sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
+    if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
     if (P.stem) {
         StemParams q;
         q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
-        const unsigned long long ybytes = M64 * (unsigned long long)d->Cout * P.ES;
+        q.Hq = pool ? pool_out(P.Ho, 3, 2, 1, 0) : P.Ho;
+        q.Wq = pool ? pool_out(P.Wo, 3, 2, 1, 0) : P.Wo;
+        const unsigned long long ybytes = (unsigned long long)d->N * q.Hq * q.Wq * (unsigned long long)d->Cout * P.ES;
         if (ybytes >= 0x80000000ull)
             return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
         q.y_bytes = (uint32_t)ybytes;
         q.N = d->N; q.H = d->H; q.W = d->W; q.Wp = wpitch; q.Ho = P.Ho; q.Wo = P.Wo; q.Cout = d->Cout;
         q.kh = d->kh; q.pt = d->pad_t; q.x0off = -(d->pad_l + (d->pad_l & 1));
-        q.tilesH = (P.Ho + 15) / 16; q.tilesW = (P.Wo + 15) / 16;
+        q.tilesH = pool ? (q.Hq + 6) / 7 : (P.Ho + 15) / 16;
+        q.tilesW = pool ? (q.Wq + 6) / 7 : (P.Wo + 15) / 16;
         const long long nT = (long long)d->N * q.tilesH * q.tilesW;
         if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
         q.nTiles = (int)nT;
@@ -783,8 +793,11 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
         long long nb = (long long)ctx->num_cu * g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1];
         if (nb > nT) nb = nT;
         nb = (nb + 7) / 8 * 8;
-        if (d->dtype == PCV_BF16) hipLaunchKernelGGL(stem_conv_kernel<PCV_BF16>, dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL(stem_conv_kernel<PCV_F16>, dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        if (pool) {
+            if (d->dtype == PCV_BF16) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+            else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        } else if (d->dtype == PCV_BF16) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
@@ -943,6 +956,26 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
     hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
+}
+
+int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                     const float* shift, const void* residual, void* y, void* stream) {
+    return conv2d_impl(ctx, d, x, packed, scale, shift, residual, y, stream, false);
+}
+
+int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, int ceil_mode) {
+    if (!d || k != 3 || s != 2 || p != 1 || ceil_mode) return 0;
+    ConvPlan P;
+    if (plan_conv(*d, P, false) != nullptr || !P.stem) return 0;
+    return (d->has_residual || d->post_act != PCV_ACT_NONE || (d->y_cpitch > 0 && d->y_cpitch != d->Cout)) ? 0 : 1;
+}
+
+int pcv_conv2d_maxpool_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                             const float* shift, void* y, int k, int s, int p, int ceil_mode, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!pcv_conv2d_maxpool_supported(d, k, s, p, ceil_mode))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution followed by MaxPool2d(3, 2, 1) is covered");
+    return conv2d_impl(ctx, d, x, packed, scale, shift, nullptr, y, stream, true);
 }
 
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,

@@ -9,6 +9,13 @@
 // 2*fr + 2*fq of patch row 2*orow + r - consecutive lanes read consecutive 16-byte slots, so the overlapping windows
 // cost nothing. One filter row = one K=32 MFMA step (8 pixels x 4 channels; the leading pad pixel and channel 3 carry
 // zero weights). The weights (Cout x kh x 32, <= 28 KB) stay resident in LDS for the whole persistent block.
+//
+// POOL variant: the MaxPool2d(3, stride 2, pad 1) that follows the stem in the ResNet-style init blocks (resnet.py:255-258)
+// in the same launch. A block then owns a 7x7 tile of POOLED pixels = conv rows/cols 14t-1 .. 14t+13 of its 16x16 conv tile
+// (1.31x the MFMA work), and the 112x112x64 conv output (411 MB written + read at batch 256) never exists: after BN +
+// activation the 3-wide column max runs across lanes with DPP row shifts (a 16-lane DPP row = the 16 conv columns of one
+// fragment), the 3-high row max in registers (a wave holds 4 consecutive conv rows) plus one row handed down from the next
+// wave through LDS. max() commutes with the monotonic rounding, so the result equals pooling the rounded tensor bit for bit.
 #pragma once
 #include "pcv_common.hpp"
 #include "igemm_conv.hpp"     // Mma<DT>
@@ -26,10 +33,17 @@ struct StemParams {
     int x0off;                // patch column origin relative to 2*wo0 (= -(pl + (pl & 1)))
     int tilesH, tilesW, nTiles;
     int act;
+    int Hq, Wq;               // POOL: pooled output size; y is [N, Hq, Wq, Cout]
 };
 
+__device__ __forceinline__ float stem_row_shl(float v, int n) {      // value of lane fr + n of the same 16-lane row (0 past the end)
+    const int i = __builtin_bit_cast(int, v);
+    const int r = n == 1 ? __builtin_amdgcn_update_dpp(0, i, 0x101, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, i, 0x102, 0xF, 0xF, true);
+    return __builtin_bit_cast(float, r);
+}
+
 // 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 64 (padded) channels.
-template <int DT>
+template <int DT, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 16, TW = 16;
@@ -39,7 +53,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
     constexpr int WBYTES = 7 * 64 * 64;          // weights: up to 7 filter rows x 64 rows x 64 B
     constexpr int PBYTES = PCHUNKS * 16;
     typedef typename Mma<DT>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights | patch 0 | patch 1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights | patch 0 | patch 1 | POOL: row hand-down 6 KB]
+    constexpr int TSTEP = POOL ? 14 : 16;        // conv rows / columns between tile origins
+    constexpr int TORG = POOL ? -1 : 0;          // first conv row / column of tile 0
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         const int t2 = t / p.tilesW;
         const int th = t2 % p.tilesH;
         const int n = t2 / p.tilesH;
-        const int hi0 = th * TH * 2 - p.pt;
-        const int wp0 = tw * TW * 2 + p.x0off;                   // even
+        const int hi0 = (th * TSTEP + TORG) * 2 - p.pt;
+        const int wp0 = (tw * TSTEP + TORG) * 2 + p.x0off;       // even
         char* dst0 = smem + WBYTES + buf * PBYTES;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -147,6 +163,71 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         const int t2 = tile / p.tilesW;
         const int th = t2 % p.tilesH;
         const int n = t2 / p.tilesH;
+        if constexpr (POOL) {
+            // conv position of this lane: row (14 th - 1) + 4 wave + j, column (14 tw - 1) + fr; outside the conv output = -inf
+            const int wo = tw * TSTEP + TORG + fr;
+            const bool colok = (unsigned)wo < (unsigned)p.Wo;
+            const float NEG = -__builtin_huge_valf();
+            char* const hand = smem + WBYTES + 2 * PBYTES;      // [wave 1..3][ip][lane] x 16 bytes
+            u32x4 top[2];                                       // this wave's first row after the column max (for the wave above)
+            u32x4 mid[2], bot[2];                               // pooled rows 2 wave (rows j = 0..2) and 2 wave + 1 (rows j = 2, 3 + next wave)
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                float h[4][8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ho = th * TSTEP + TORG + 4 * wave + j;
+                    const bool ok = colok && (unsigned)ho < (unsigned)p.Ho;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
+                        v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
+                    }
+                    apply_act8(v, act);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float c0 = ok ? v[e] : NEG;
+                        // lanes fr + 1, fr + 2 of the same row; DPP returns 0 past lane 15, only fr <= 12 is used below
+                        h[j][e] = fmaxf(c0, fmaxf(stem_row_shl(c0, 1), stem_row_shl(c0, 2)));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    top[ip][e] = pack2<DT>(h[0][2 * e], h[0][2 * e + 1]);
+                    mid[ip][e] = pack2<DT>(fmaxf(h[0][2 * e], fmaxf(h[1][2 * e], h[2][2 * e])),
+                                           fmaxf(h[0][2 * e + 1], fmaxf(h[1][2 * e + 1], h[2][2 * e + 1])));
+                    bot[ip][e] = pack2<DT>(fmaxf(h[2][2 * e], h[3][2 * e]), fmaxf(h[2][2 * e + 1], h[3][2 * e + 1]));
+                }
+                if (wave > 0) *reinterpret_cast<u32x4*>(hand + (((wave - 1) * 2 + ip) * 64 + lane) * 16) = top[ip];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the hand-down rows are written; the next patch's DMA stays in flight
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int qo = tw * 7 + (fr >> 1);
+            const bool lane_ok = (fr & 1) == 0 && fr <= 12 && qo < p.Wq;
+#pragma unroll
+            for (int ip = 0; ip < 2; ++ip) {
+                const int ch0 = 32 * ip + 8 * fq;
+                if (wave < 3) {
+                    const u32x4 nx = *reinterpret_cast<const u32x4*>(hand + ((wave * 2 + ip) * 64 + lane) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a0, a1, b0, b1;
+                        unpack2<DT>(bot[ip][e], a0, a1);
+                        unpack2<DT>(nx[e], b0, b1);
+                        bot[ip][e] = pack2<DT>(fmaxf(a0, b0), fmaxf(a1, b1));
+                    }
+                }
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int po = th * 7 + 2 * wave + half;                   // pooled row
+                    const bool ok = lane_ok && ch0 < p.Cout && po < p.Hq && (half == 0 || wave < 3);
+                    const uint32_t boff = ok ? (uint32_t)(((((n * p.Hq + po) * p.Wq + qo)) * p.Cout + ch0) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(half == 0 ? mid[ip] : bot[ip], yrsrc, boff, 0, 0);
+                }
+            }
+        } else {
         const int wo = tw * TW + fr;
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip) {
@@ -168,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
                 const uint32_t boff = ok ? (uint32_t)(((((n * p.Ho + ho) * p.Wo + wo)) * p.Cout + ch0) * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
             }
+        }
         }
         if (!has_next) break;
         tile = ntile;

@@ -279,6 +279,28 @@ class ConvRunner(object):
         self.prepare(x, d)
         return self._launch(x, d, residual, out)
 
+    def run_maxpool(self, x: NHWC, act: int, k: int, s: int, p: int, ceil_mode: bool = False):
+        """This convolution + BN + activation and the MaxPool2d(k, s, p) behind it as ONE launch when covered
+        (pcv_conv2d_maxpool_fused: the stem convolution with MaxPool2d(3, 2, 1)); returns the pooled handle or None."""
+        if not FUSE_UNITS or self.depthwise or self.pad4 is not None:
+            return None
+        if self.bn is not None and self.bn.training:
+            raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        d = self.desc(x, act, 0, False)
+        L, ctx = _lib.lib(), _ctx(x.device)
+        if not L.pcv_conv2d_maxpool_supported(ctypes.byref(d), k, s, p, 1 if ceil_mode else 0):
+            return None
+        self.prepare(x, d)
+        Ho = (x.H + d.pad_t + d.pad_b - d.dil_h * (d.kh - 1) - 1) // d.stride_h + 1
+        Wo = (x.W + d.pad_l + d.pad_r - d.dil_w * (d.kw - 1) - 1) // d.stride_w + 1
+        Hq, Wq = (Ho + 2 * p - k) // s + 1, (Wo + 2 * p - k) // s + 1
+        if Hq <= 0 or Wq <= 0:
+            return None
+        y = torch.empty((x.N, Hq, Wq, d.Cout), dtype=x.dtype, device=x.device)
+        _lib.check(L.pcv_conv2d_maxpool_fused(ctx, ctypes.byref(d), _ptr(x.t), _ptr(self.packed), _ptr(self.scale), _ptr(self.shift),
+                                              _ptr(y), k, s, p, 1 if ceil_mode else 0, _stream(x.device)), ctx)
+        return NHWC(y, x.N, Hq, Wq, self.conv.out_channels, cpitch=d.Cout)
+
     def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
         """This convolution (+ residual, + post_act) and the 1x1 convolution `nxt` that consumes its output, as ONE launch
         (pcv_conv1x1_pair_fused): returns (y1, y2), or None when the pair of shapes is not covered by the fused kernel."""

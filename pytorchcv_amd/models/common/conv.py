@@ -7,7 +7,7 @@
 
 __all__ = ['conv1x1', 'conv3x3', 'depthwise_conv3x3', 'ConvBlock', 'conv1x1_block', 'conv3x3_block', 'conv5x5_block',
            'conv7x7_block', 'dwconv_block', 'dwconv3x3_block', 'dwconv5x5_block', 'DwsConvBlock', 'dwsconv3x3_block', 'BareConv', 'PreConvBlock',
-           'pre_conv1x1_block', 'pre_conv3x3_block', 'conv_block_pair', 'mbconv_chain']
+           'pre_conv1x1_block', 'pre_conv3x3_block', 'conv_block_pair', 'conv_block_maxpool', 'mbconv_chain']
 
 import torch.nn as nn
 from .activ import lambda_relu, create_activation_layer
@@ -76,6 +76,19 @@ class ConvBlock(nn.Module):
         pact = engine.act_code(post_act)
         return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact,
                                                                        pad4=pad4))
+
+
+def conv_block_maxpool(block, x, pool):
+    """ConvBlock `block` followed by the MaxPool2dNHWC `pool` (an init block's `conv` -> `pool`): one fused launch when covered
+    (pcv_conv2d_maxpool_fused), else the two launches."""
+    if isinstance(block, ConvBlock) and isinstance(x, engine.NHWC) and not block.use_pad:
+        if block._pcv_runner is None:
+            block._pcv_runner = engine.ConvRunner(block.conv, block.bn if block.normalize else None, pad4=block._pad4)
+        y = block._pcv_runner.run_maxpool(x, engine.act_code(block.activ) if block.activate else 0, pool.kernel_size,
+                                          pool.stride, pool.padding, pool.ceil_mode)
+        if y is not None:
+            return y
+    return pool(block(x))
 
 
 def conv_block_pair(first, x, residual, post_act, second, id_block=None, x0=None):

@@ -113,7 +113,9 @@ class PreResInitBlock(nn.Module):
     def _run(self, a):
         if self._pcv_runner is None:
             self._pcv_runner = engine.ConvRunner(self.conv, self.bn)
-        return self.pool(self._pcv_runner.run(a, act=engine.act_code(self.activ)))
+        y = self._pcv_runner.run_maxpool(a, engine.act_code(self.activ), self.pool.kernel_size, self.pool.stride, self.pool.padding,
+                                         self.pool.ceil_mode)
+        return y if y is not None else self.pool(self._pcv_runner.run(a, act=engine.act_code(self.activ)))
 
     def forward(self, x):
         return engine.boundary(self, x, self._run, stem=True)

@@ -11,7 +11,7 @@ __all__ = ['ResNet', 'resnet10', 'resnet12', 'resnet14', 'resnetbc14b', 'resnet1
 import torch.nn as nn
 from .common.activ import lambda_relu
 from .common.norm import lambda_batchnorm2d
-from .common.conv import conv1x1_block, conv3x3_block, conv7x7_block, conv_block_pair
+from .common.conv import conv1x1_block, conv3x3_block, conv7x7_block, conv_block_pair, conv_block_maxpool
 from ._tail import MaxPool2dNHWC, AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
 
@@ -117,7 +117,7 @@ class ResInitBlock(nn.Module):
         self.pool = MaxPool2dNHWC(kernel_size=3, stride=2, padding=1)
 
     def forward(self, x):
-        return engine.boundary(self, x, lambda a: self.pool(self.conv(a)), stem=True)
+        return engine.boundary(self, x, lambda a: conv_block_maxpool(self.conv, a, self.pool), stem=True)
 
 
 class ResNet(nn.Module):

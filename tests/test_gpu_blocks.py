@@ -297,3 +297,29 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, cuda_de
     ref = refnet.conv_block(sdc, "conv3.", t, act=None, q=q, residual=(xr if unit.residual else None))
     err = float((f.permute(0, 3, 1, 2) - ref).abs().max())
     assert err <= 1e-2 * max(1.0, float(ref.abs().max())), err
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 32, 32), (2, 33, 35), (1, 70, 50), (2, 61, 224), (1, 30, 30)])
+def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, cuda_device):
+    """pcv_conv2d_maxpool_fused (7x7/2 stem + BN + ReLU + MaxPool2d(3, 2, 1) in one launch) is bit-identical to the stem
+    launch followed by pcv_maxpool2d, including odd sizes where pooling windows hang over the border."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.resnet import ResInitBlock
+    N, H, W = shape
+    blk = ResInitBlock(in_channels=3, out_channels=64).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=77))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, 3, H, W, seed=78).to(cuda_device)
+    with torch.no_grad():
+        a = engine.from_nchw(x, dtype, stem=True)
+        fused = blk.conv._pcv_runner.run_maxpool(a, 1, 3, 2, 1) if blk.conv._pcv_runner is not None else None
+        if fused is None:
+            blk(x)                                  # builds the runner
+            fused = blk.conv._pcv_runner.run_maxpool(a, 1, 3, 2, 1)
+        assert fused is not None, "the 7x7/2 stem + MaxPool2d(3, 2, 1) must be covered by the fused kernel"
+        two = blk.pool(blk.conv(a))
+    torch.cuda.synchronize()
+    assert fused.t.shape == two.t.shape and (fused.H, fused.W) == (two.H, two.W)
+    assert torch.equal(fused.t, two.t)
