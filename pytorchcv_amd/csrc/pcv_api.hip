@@ -14,6 +14,7 @@
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
+#include "c64conv3x3.hpp"
 #include "mbconv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
@@ -38,6 +39,8 @@ struct pcv_ctx {
     int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int use_c64 = 0;            // register-resident-weights 3x3 kernel for 64 -> 64 channels (c64conv3x3.hpp): no faster than the
+                                // generic tile (one wave per SIMD is issue-bound), so it is off; pcv_set_tuning("c64", 1) enables it
     int use_hconv = 0;          // halo-reuse 3x3 kernel (hconv3x3.hpp) for the eligible 3x3/s1/p1 layers
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
@@ -346,6 +349,14 @@ static hconv_fn pick_hconv(int dt, int cfg) {
     if (dt == PCV_F16) return hconv_for<PCV_F16>(cfg);
     return hconv_for<PCV_F32>(cfg);
 }
+static int enable_c64(pcv_ctx* ctx) {
+    const void* fns[4] = {reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_BF16, false>),
+                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_BF16, true>),
+                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, false>),
+                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, true>)};
+    for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kC64Lds));
+    return PCV_OK;
+}
 static int enable_hconv(pcv_ctx* ctx) {
     for (int dt = 0; dt < 3; ++dt)
         for (int cfg = 0; cfg < 2; ++cfg)
@@ -560,6 +571,7 @@ int pcv_create(pcv_ctx** out, int device) {
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc == PCV_OK) rc = enable_hconv(ctx);
+    if (rc == PCV_OK) rc = enable_c64(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc == PCV_OK) rc = enable_mbconv(ctx);
@@ -588,6 +600,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "pair_pb") ctx->pair_pb = value;
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "hconv") ctx->use_hconv = value;
+    else if (k == "c64") ctx->use_c64 = value;
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
@@ -802,6 +815,38 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return PCV_OK;
     }
 
+    if (P.conv3 && ctx->use_c64 && !sliced_y && d->Cin == 64 && d->Cout == 64 && d->W <= 63 && d->dtype != PCV_F32 &&
+        (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * 64ull * 2ull < 0x80000000ull && P.Kpad == 576) {
+        HConvParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
+        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
+        q.y_bytes = (uint32_t)(M64 * 64ull * 2ull);
+        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = 64; q.Cout = 64;
+        q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.CS = 1; q.Kpad = P.Kpad;
+        q.act = d->act; q.post_act = d->post_act;
+        q.nChTiles = 1;
+        const long long nT = (long long)((M64 + 255) / 256);
+        q.nTiles = (int)nT;
+        long long nb = (long long)ctx->num_cu;                        // one 512-register block per CU
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        const bool bf = d->dtype == PCV_BF16;
+        hipStream_t st = (hipStream_t)stream;
+        if (d->has_residual) {
+            if (bf) c64conv3x3_kernel<PCV_BF16, true><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
+            else c64conv3x3_kernel<PCV_F16, true><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
+        } else {
+            if (bf) c64conv3x3_kernel<PCV_BF16, false><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
+            else c64conv3x3_kernel<PCV_F16, false><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
     if (P.conv3 && ctx->use_hconv && !sliced_y && d->W <= 63 && d->Cout % 8 == 0 && d->out_dtype == d->dtype &&
         (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * (unsigned long long)d->Cout * P.ES < 0x80000000ull) {
         HConvParams q;

@@ -139,6 +139,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
     from pytorchcv_amd import _lib
     ctx = _lib.ctx_for(0)
     _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 1 if use_conv3 is True else 0), ctx)
+    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 0), ctx)    # the 64 -> 64 kernel has its own test below
     hconv_default = 0                                             # restored below (the product default: off)
     _lib.check(_lib.lib().pcv_set_tuning(ctx, b"hconv", 1 if use_conv3 == "hconv" else 0), ctx)
     x = util.synth_input(N, C, H, W, seed=21)
@@ -323,3 +324,42 @@ def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, cuda_device):
     torch.cuda.synchronize()
     assert fused.t.shape == two.t.shape and (fused.H, fused.W) == (two.H, two.W)
     assert torch.equal(fused.t, two.t)
+
+
+_C64_SHAPES = [(2, 56, 56), (1, 5, 63), (40, 9, 5), (3, 7, 7), (1, 1, 1), (9, 28, 28), (2, 63, 63), (7, 14, 30)]
+
+
+@pytest.mark.parametrize("use_res", [False, True], ids=["plain", "res"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _C64_SHAPES, ids=["x".join(str(v) for v in s) for s in _C64_SHAPES])
+def test_c64_conv3x3_kernel_equals_generic_and_oracle(shape, dtype, use_res, cuda_device):
+    """c64conv3x3_kernel (64 -> 64 channels, all weights in registers, halo tile staged once): bit-identical to the generic
+    implicit GEMM (same K order) and within the 16-bit bound of the oracle; multi-tile, tile tails, many image borders per tile,
+    the widest supported map (W = 63) and a single pixel."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine, _lib
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, H, W = shape
+    blk = conv3x3_block(in_channels=64, out_channels=64).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=91)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    ctx = _lib.ctx_for(0)
+    x = util.synth_input(N, 64, H, W, seed=92)
+    res = util.synth_input(N, 64, H, W, seed=93) if use_res else None
+    relu = torch.nn.ReLU() if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 1), ctx)
+        y_new = blk(xh, residual=rh, post_act=relu).t.clone()
+        _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 0), ctx)
+        y_gen = blk(xh, residual=rh, post_act=relu)
+        y = engine.to_nchw(engine.NHWC(y_new, N, H, W, 64)).cpu()
+    torch.cuda.synchronize()
+    assert torch.equal(y_new, y_gen.t)
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
