@@ -247,6 +247,9 @@ def main():
         fuse_was = _engine.FUSE_UNITS
         if klass == "depthwise":
             _engine.FUSE_UNITS = False               # time the depthwise KERNEL on every layer (the fused units bypass it)
+        with torch.no_grad():
+            net(x)                                   # untimed: first use of the per-layer kernels this pass takes (code load, packing)
+        torch.cuda.synchronize()
         with LaunchTimer(klass) as lt:
             for _ in range(max(3, min(args.steps, 10))):
                 with torch.no_grad():
