@@ -387,7 +387,30 @@ static int pair_lds(int pb, bool idc = false) { return (idc ? 6 : 3) * 16 * pb *
 static int g_pair_idc_blocks_per_cu = 1;
 static int g_pair_blocks_per_cu[2] = {1, 1};                                        // [PB == 4, PB == 2]
 static int g_wpair_mask = 3;                                                        // bit 0: CM = 128, bit 1: CM = 256 (tuning)
-static int g_wpair_blocks_per_cu[2] = {1, 1};                                       // wpair1x1_kernel<*, 128 | 256>
+static int g_wpair_blocks_per_cu[4] = {1, 1, 1, 1};
+// wide pair configurations: 0: 128 -> 512, 1: 256 -> 1024 (ResNet), 2: 128 -> 256, 3: 256 -> 512 (ResNeXt 32x4d)
+struct WPairLaunch { const void* fn; int threads, lds, tileP; };
+template <int CM, int C1> static WPairLaunch wpair_launch_for(int dt) {
+    typedef WPairCfg<CM, C1> G;
+    const void* fn = dt == PCV_BF16 ? reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, CM, C1>)
+                                    : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1>);
+    return WPairLaunch{fn, 64 * G::NW, G::LDS, G::P};
+}
+static WPairLaunch wpair_launch(int cfg, int dt) {
+    switch (cfg) {
+        case 0: return wpair_launch_for<128, 512>(dt);
+        case 1: return wpair_launch_for<256, 1024>(dt);
+        case 2: return wpair_launch_for<128, 256>(dt);
+        default: return wpair_launch_for<256, 512>(dt);
+    }
+}
+static int wpair_cfg(int cm, int c1) {
+    if (cm == 128 && c1 == 512) return 0;
+    if (cm == 256 && c1 == 1024) return 1;
+    if (cm == 128 && c1 == 256) return 2;
+    if (cm == 256 && c1 == 512) return 3;
+    return -1;
+}
 static int enable_pair(pcv_ctx* ctx) {
     const void* fns[4] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 4>),
                           reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 4>),
@@ -408,17 +431,14 @@ static int enable_pair(pcv_ctx* ctx) {
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, idc[i], 256, pair_lds(2, true)));
         g_pair_idc_blocks_per_cu = nb < 1 ? 1 : nb;
     }
-    const void* wide[4] = {reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 128>),
-                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 128>),
-                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, 256>),
-                           reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, 256>)};
-    for (int i = 0; i < 4; ++i) {
-        const int lds = i < 2 ? WPairCfg<128>::LDS : WPairCfg<256>::LDS;
-        HIP_TRY(ctx, hipFuncSetAttribute(wide[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int nb = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wide[i], i < 2 ? 64 * WPairCfg<128>::NW : 64 * WPairCfg<256>::NW, lds));
-        g_wpair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
-    }
+    for (int cfg = 0; cfg < 4; ++cfg)
+        for (int dt = PCV_BF16; dt <= PCV_F16; ++dt) {
+            const WPairLaunch L = wpair_launch(cfg, dt);
+            HIP_TRY(ctx, hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+            int nb = 0;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, L.fn, L.threads, L.lds));
+            g_wpair_blocks_per_cu[cfg] = nb < 1 ? 1 : nb;
+        }
     return PCV_OK;
 }
 // Which (conv, next conv) pairs the fused kernel covers: 1x1/s1 64 -> 256 with residual, then 1x1/s1 256 -> 64, 16 bit.
@@ -433,9 +453,9 @@ static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc&
     if (a.dtype != b.dtype || (a.dtype != PCV_BF16 && a.dtype != PCV_F16)) return "16-bit storage only";
     if (a.N != b.N || a.H != b.H || a.W != b.W || a.Cout != b.Cin) return "shapes do not chain";
     const bool narrow = a.Cin == 64 && a.Cout == 256 && b.Cout == 64;        // pair1x1.hpp: weights in registers
-    const bool wide = ((a.Cin == 128 && (g_wpair_mask & 1)) || (a.Cin == 256 && (g_wpair_mask & 2))) && a.Cout == 4 * a.Cin &&
-                      b.Cout == a.Cin;   // wpair1x1.hpp: weights through an LDS ring
-    if (!narrow && !wide) return "only 64 -> 256 -> 64, 128 -> 512 -> 128 and 256 -> 1024 -> 256 are instantiated";
+    const bool wide = ((a.Cin == 128 && (g_wpair_mask & 1)) || (a.Cin == 256 && (g_wpair_mask & 2))) &&
+                      wpair_cfg(a.Cin, a.Cout) >= 0 && b.Cout == a.Cin;   // wpair1x1.hpp: weights through an LDS ring
+    if (!narrow && !wide) return "only 64 -> 256 -> 64, 128 -> 512|256 -> 128 and 256 -> 1024|512 -> 256 are instantiated";
     if (!a.has_residual || b.has_residual || b.post_act != PCV_ACT_NONE) return "first conv must carry the residual, second must not";
     if ((long)a.N * a.H * a.W * a.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
     return nullptr;
@@ -1220,8 +1240,8 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
     const long M = (long)d1->N * d1->H * d1->W;
     hipStream_t st = (hipStream_t)stream;
     if (d1->Cin >= 128) {
-        const int CM = d1->Cin, C1 = 4 * CM;
-        if (P1.wrows != C1 || P1.Kpad != CM || P2.wrows != CM || P2.Kpad != C1 || P1.ngb != 1 || P2.ngb != 1)
+        const int CM = d1->Cin, C1 = d1->Cout, cfg = wpair_cfg(CM, C1);
+        if (cfg < 0 || P1.wrows != C1 || P1.Kpad != CM || P2.wrows != CM || P2.Kpad != C1 || P1.ngb != 1 || P2.ngb != 1)
             return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
         WPairParams q;
         std::memset(&q, 0, sizeof(q));
@@ -1231,19 +1251,12 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
         q.x_bytes = q.y2_bytes = (uint32_t)(M * CM * 2); q.res_bytes = q.y1_bytes = (uint32_t)(M * C1 * 2);
         q.w1_bytes = q.w2_bytes = (uint32_t)(C1 * CM * 2);
-        const int tileP = CM == 128 ? WPairCfg<128>::P : WPairCfg<256>::P;
-        q.M = (int)M; q.nTiles = (int)((M + tileP - 1) / tileP);
+        const WPairLaunch L = wpair_launch(cfg, d1->dtype);
+        q.M = (int)M; q.nTiles = (int)((M + L.tileP - 1) / L.tileP);
         q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
-        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[CM == 128 ? 0 : 1]);
-        const bool bf = d1->dtype == PCV_BF16;
-        if (CM == 128) {
-            if (bf) wpair1x1_kernel<PCV_BF16, 128><<<grid, 256, WPairCfg<128>::LDS, st>>>(q);
-            else wpair1x1_kernel<PCV_F16, 128><<<grid, 256, WPairCfg<128>::LDS, st>>>(q);
-        } else {
-            if (bf) wpair1x1_kernel<PCV_BF16, 256><<<grid, 64 * WPairCfg<256>::NW, WPairCfg<256>::LDS, st>>>(q);
-            else wpair1x1_kernel<PCV_F16, 256><<<grid, 64 * WPairCfg<256>::NW, WPairCfg<256>::LDS, st>>>(q);
-        }
-        HIP_TRY(ctx, hipGetLastError());
+        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[cfg]);
+        void* args[] = {&q};
+        HIP_TRY(ctx, hipLaunchKernel(L.fn, dim3(grid), dim3((unsigned)L.threads), args, (size_t)L.lds, st));
         return PCV_OK;
     }
     if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || P1.ngb != 1 || P2.ngb != 1)

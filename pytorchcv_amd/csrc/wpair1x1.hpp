@@ -1,6 +1,7 @@
 // wpair1x1.hpp - the fused 1x1 pair of pair1x1.hpp for the WIDER bottleneck stages: the last convolution of a unit
 // (CM -> 4 CM, BN, + identity, ReLU; reference resnet.py:227-228) and the first convolution of the next unit
-// (4 CM -> CM, BN, ReLU; resnet.py:106-109), CM = 128 / 256 (ResNet-50/101/152 stages 2 and 3), 16-bit storage.
+// (4 CM -> CM, BN, ReLU; resnet.py:106-109), CM = 128 / 256 (ResNet-50/101/152 stages 2 and 3), 16-bit storage. The same with
+// C1 = 2 CM covers ResNeXt 32x4d stages 1 and 2 (128 -> 256 -> 128, 256 -> 512 -> 256; resnext.py:62-80).
 //
 // Both layers are HBM-bound when run separately (57 FLOP/B at CM = 128) and the second one re-reads the 4 CM-channel
 // tensor the first has just written: 717 MB per pair at batch 256 against 512 MB when y1 goes straight from the first
@@ -49,8 +50,8 @@ template <int N> __device__ __forceinline__ void wpair_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int CM> struct WPairCfg {
-    static constexpr int C1 = 4 * CM;
+template <int CM, int C1_ = 4 * CM> struct WPairCfg {
+    static constexpr int C1 = C1_;                      // 4 CM in ResNet, 2 CM in ResNeXt 32x4d (resnext.py:62-80)
     static constexpr bool PAIRW = CM > 128;             // pairs of waves share their pixels and split the channels
     static constexpr int NWC = PAIRW ? 2 : 1;           // waves along the channels
     static constexpr int NWP = 4;                       // waves along the pixels
@@ -68,10 +69,10 @@ template <int CM> struct WPairCfg {
     static constexpr int LDS = TAB + (2 * C1 + 2 * CM) * 4;
 };
 
-template <int DT, int CM>
-__global__ __launch_bounds__(64 * WPairCfg<CM>::NW, 2) void wpair1x1_kernel(const WPairParams p) {   // 2 waves per SIMD: 256 registers
+template <int DT, int CM, int C1_ = 4 * CM>
+__global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kernel(const WPairParams p) {   // 2 waves per SIMD: 256 registers
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef WPairCfg<CM> G;
+    typedef WPairCfg<CM, C1_> G;
     constexpr int C1 = G::C1, P = G::P, NCH = G::NCH, KS1 = G::KS1, PBW = G::PBW, NWC = G::NWC;
     constexpr bool PAIRW = G::PAIRW;
     constexpr int NW = G::NW, NT = 64 * NW;

@@ -101,7 +101,8 @@ class ResStage(nn.Sequential):
     first one can share a launch."""
     def forward(self, x):
         units = list(self.children())
-        if not isinstance(x, engine.NHWC) or not all(isinstance(u, ResUnit) and isinstance(u.body, ResBottleneck) for u in units):
+        chainable = all((isinstance(u, ResUnit) and isinstance(u.body, ResBottleneck)) or getattr(u, "pcv_chainable", False) for u in units)
+        if not isinstance(x, engine.NHWC) or not chainable:
             return super(ResStage, self).forward(x)
         conv1_out = None
         for i, unit in enumerate(units):

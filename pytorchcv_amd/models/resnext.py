@@ -8,8 +8,8 @@ __all__ = ['ResNeXt', 'resnext14_16x4d', 'resnext14_32x2d', 'resnext14_32x4d', '
 
 import math
 import torch.nn as nn
-from .common.conv import conv1x1_block, conv3x3_block
-from .resnet import ResInitBlock
+from .common.conv import conv1x1_block, conv3x3_block, conv_block_pair
+from .resnet import ResInitBlock, ResStage
 from ._tail import AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
 
@@ -39,9 +39,23 @@ class ResNeXtUnit(nn.Module):
                                                activation=None)
         self.activ = nn.ReLU(inplace=True)
 
+    pcv_chainable = True         # ResStage may hand this unit its first convolution's output and fuse its last one forward
+
     def _run(self, a):
         identity = self.identity_conv(a) if self.resize_identity else a
         return self.body(a, residual=identity, post_act=self.activ)
+
+    def run_chained(self, a, conv1_out=None, next_unit=None):
+        """As ResUnit.run_chained: the unit's last 1x1 (+ skip add + ReLU) and the next unit's first 1x1 as one launch when the
+        pair is covered (128 -> 256 -> 128 and 256 -> 512 -> 256 in the 32x4d nets)."""
+        identity = self.identity_conv(a) if self.resize_identity else a
+        body = self.body
+        y = body.conv2(conv1_out if conv1_out is not None else body.conv1(a))
+        if next_unit is not None:
+            pair = conv_block_pair(body.conv3, y, identity, self.activ, next_unit.body.conv1)
+            if pair is not None:
+                return pair
+        return body.conv3(y, residual=identity, post_act=self.activ), None
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)
@@ -57,7 +71,7 @@ class ResNeXt(nn.Module):
         self.features.add_module("init_block", ResInitBlock(in_channels=in_channels, out_channels=init_block_channels))
         in_channels = init_block_channels
         for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
+            stage = ResStage()
             for j, out_channels in enumerate(channels_per_stage):
                 stride = 2 if (j == 0) and (i != 0) else 1
                 stage.add_module("unit{}".format(j + 1), ResNeXtUnit(in_channels=in_channels, out_channels=out_channels,

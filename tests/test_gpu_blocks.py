@@ -161,7 +161,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("cm", [64, 128, 256])
+@pytest.mark.parametrize("cm", [64, 128, 256, (128, 256), (256, 512)], ids=["64x4", "128x4", "256x4", "128x2", "256x2"])
 @pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 8, 8), (5, 28, 28), (9, 14, 14)])
 def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     """pcv_conv1x1_pair_fused (unit's last 1x1 + skip add + ReLU, then the next unit's first 1x1) against the same two
@@ -171,8 +171,9 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv1x1_block, conv_block_pair
     N, H, W = shape
-    first = conv1x1_block(in_channels=cm, out_channels=4 * cm, activation=None).eval()
-    second = conv1x1_block(in_channels=4 * cm, out_channels=cm).eval()
+    cm, c1 = cm if isinstance(cm, tuple) else (cm, 4 * cm)      # ResNet: 4x, ResNeXt 32x4d: 2x
+    first = conv1x1_block(in_channels=cm, out_channels=c1, activation=None).eval()
+    second = conv1x1_block(in_channels=c1, out_channels=cm).eval()
     first.load_state_dict(util.synth_state_dict(first.state_dict(), seed=21))
     second.load_state_dict(util.synth_state_dict(second.state_dict(), seed=22))
     first = pytorchcv_amd.set_compute_dtype(first.to(cuda_device), dtype)
@@ -180,7 +181,7 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
     g = torch.Generator().manual_seed(5)
     x = engine.NHWC(torch.randn((N, H, W, cm), generator=g).to(cuda_device).to(tdt), N, H, W, cm)
-    r = engine.NHWC(torch.randn((N, H, W, 4 * cm), generator=g).to(cuda_device).to(tdt), N, H, W, 4 * cm)
+    r = engine.NHWC(torch.randn((N, H, W, c1), generator=g).to(cuda_device).to(tdt), N, H, W, c1)
     relu = nn.ReLU()
     with torch.no_grad():
         y1_ref = first(x, residual=r, post_act=relu)
