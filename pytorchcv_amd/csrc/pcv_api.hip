@@ -15,6 +15,7 @@
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
 #include "c64conv3x3.hpp"
+#include "gconv3x3.hpp"
 #include "mbconv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
@@ -93,6 +94,8 @@ struct ConvPlan {
     int nchunks = 0, nk = 0, Kpad = 0;
     int wrows = 0;
     size_t ktab_bytes = 0, w_bytes = 0, total_bytes = 0;
+    bool gconv = false;       // grouped 3x3/s1/p1 with 4/8/16 channels per group: a second blob for gconv3x3.hpp follows the generic
+    size_t gconv_off = 0;     // one (the choice between the two kernels depends on the map width, known only at launch)
     std::vector<uint32_t> ktab;   // built only when tables == true
     std::vector<uint32_t> ksrc;
 };
@@ -162,6 +165,16 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
     P.ktab_bytes = (size_t)round_up(P.nk * 8 * 8, 256);
     P.w_bytes = (size_t)P.ngb * P.wrows * P.Kpad * P.ES;
     P.total_bytes = P.ktab_bytes + P.w_bytes;
+    // grouped 3x3: a second blob in gconv3x3.hpp's layout behind the generic one (everything here is static; whether the launch
+    // can take that kernel also depends on the map width)
+    static const bool gconv_on = !(std::getenv("PCV_AMD_GCONV") && std::atoi(std::getenv("PCV_AMD_GCONV")) == 0);
+    P.gconv = gconv_on && d.groups > 1 && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+              d.pad_t == 1 && d.pad_l == 1 && d.pad_b == 1 && d.pad_r == 1 && d.Cin == d.Cout && d.Cin % 64 == 0 && P.ES == 2 &&
+              (P.Cg_in == 4 || P.Cg_in == 8 || P.Cg_in == 16) && d.out_dtype == d.dtype;
+    if (P.gconv) {
+        P.gconv_off = (P.total_bytes + 15) / 16 * 16;
+        P.total_bytes = P.gconv_off + (size_t)(d.Cin / 16) * 5 * 16 * 32 * P.ES;
+    }
     if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
 
     if (P.stem) {
@@ -355,6 +368,27 @@ static int enable_c64(pcv_ctx* ctx) {
                           reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, false>),
                           reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, true>)};
     for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kC64Lds));
+    return PCV_OK;
+}
+typedef void (*gconv_fn)(const GConvParams);
+struct GConvLaunch { gconv_fn fn; int lds; };
+static GConvLaunch pick_gconv(int dt, int W) {
+    const bool bf = dt == PCV_BF16;
+    if (W + 1 <= 16) return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 16> : gconv3x3_kernel<PCV_F16, 16>, GConvCfg<16>::LDS};
+    if (W + 1 <= 32) return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 32> : gconv3x3_kernel<PCV_F16, 32>, GConvCfg<32>::LDS};
+    return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 64> : gconv3x3_kernel<PCV_F16, 64>, GConvCfg<64>::LDS};
+}
+static int g_gconv_blocks_per_cu[3] = {2, 2, 2};
+static int enable_gconv(pcv_ctx* ctx) {
+    const int widths[3] = {15, 31, 63};
+    for (int i = 0; i < 3; ++i)
+        for (int dt = PCV_BF16; dt <= PCV_F16; ++dt) {
+            const GConvLaunch L = pick_gconv(dt, widths[i]);
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(L.fn), hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+            int nb = 0;
+            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(L.fn), 256, L.lds));
+            g_gconv_blocks_per_cu[i] = nb < 1 ? 1 : nb;
+        }
     return PCV_OK;
 }
 static int enable_hconv(pcv_ctx* ctx) {
@@ -592,6 +626,7 @@ int pcv_create(pcv_ctx** out, int device) {
     if (rc == PCV_OK) rc = enable_conv3(ctx);
     if (rc == PCV_OK) rc = enable_hconv(ctx);
     if (rc == PCV_OK) rc = enable_c64(ctx);
+    if (rc == PCV_OK) rc = enable_gconv(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc == PCV_OK) rc = enable_mbconv(ctx);
@@ -718,6 +753,12 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
     if (d->dtype == PCV_BF16) pack_conv_kernel<PCV_BF16><<<grid, 256, 0, s>>>(pp);
     else if (d->dtype == PCV_F16) pack_conv_kernel<PCV_F16><<<grid, 256, 0, s>>>(pp);
     else pack_conv_kernel<PCV_F32><<<grid, 256, 0, s>>>(pp);
+    if (P.gconv) {
+        const long gtotal = (long)(d->Cin / 16) * 5 * 16 * 32;
+        void* gout = static_cast<char*>(packed) + P.gconv_off;
+        if (d->dtype == PCV_BF16) pack_gconv_kernel<PCV_BF16><<<(unsigned)((gtotal + 255) / 256), 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
+        else pack_gconv_kernel<PCV_F16><<<(unsigned)((gtotal + 255) / 256), 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(ksrc_dev);
@@ -835,6 +876,31 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return PCV_OK;
     }
 
+    if (P.gconv && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && d->W <= 63 && cpitch == d->Cin &&
+        wpitch == d->W && M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull) {
+        GConvParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.y = y; q.scale = scale; q.shift = shift;
+        q.w = static_cast<const char*>(packed) + P.gconv_off;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
+        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
+        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.nPixTiles = (int)((M64 + 127) / 128);
+        const long long nT = (long long)q.nPixTiles * (d->Cin / 64);
+        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+        q.nTiles = (int)nT;
+        q.act = d->act;
+        const GConvLaunch L = pick_gconv(d->dtype, d->W);
+        const int wi = d->W + 1 <= 16 ? 0 : (d->W + 1 <= 32 ? 1 : 2);
+        long long nb = (long long)ctx->num_cu * g_gconv_blocks_per_cu[wi];
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        hipLaunchKernelGGL(L.fn, dim3((unsigned)nb), dim3(256), L.lds, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
     if (P.conv3 && ctx->use_c64 && !sliced_y && d->Cin == 64 && d->Cout == 64 && d->W <= 63 && d->dtype != PCV_F32 &&
         (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * 64ull * 2ull < 0x80000000ull && P.Kpad == 576) {
         HConvParams q;

@@ -364,3 +364,32 @@ def test_c64_conv3x3_kernel_equals_generic_and_oracle(shape, dtype, use_res, cud
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
     d = (y - ref).abs()
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
+_GCONV_SHAPES = [  # (N, C, groups, H, W): 4 / 8 / 16 channels per group, every halo width class (W <= 15, <= 31, <= 63) and beyond
+    (2, 128, 32, 56, 56), (3, 256, 32, 28, 28), (2, 512, 32, 14, 14), (1, 128, 32, 5, 63), (9, 64, 16, 9, 5), (1, 64, 4, 1, 1),
+    (2, 192, 24, 15, 31), (1, 128, 16, 3, 70), (5, 1024, 64, 7, 7),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _GCONV_SHAPES, ids=["x".join(str(v) for v in s) for s in _GCONV_SHAPES])
+def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
+    """gconv3x3_kernel (grouped 3x3 with 4 / 8 / 16 channels per group: halo tile staged once, K = tap pair x 16 channels) against
+    the oracle; W = 70 is wider than the halo scheme stages and must take the generic path with the same result."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, C, groups, H, W = shape
+    blk = conv3x3_block(in_channels=C, out_channels=C, groups=groups).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=55)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=56)
+    with torch.no_grad():
+        y = engine.to_nchw(blk(engine.from_nchw(x.to(cuda_device), dtype, stem=False))).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, groups=groups, q=q)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
