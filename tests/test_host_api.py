@@ -72,6 +72,10 @@ def test_packed_size_planning_is_pure_host_logic():
     # grouped g=32, 4 channels per group -> 4 group blocks of 32 channels, K = 9*32 = 288 -> 5 K-steps (320)
     d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128)
     assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    # ... followed by the second blob for gconv3x3_kernel: [128 / 16 slabs][5 K-steps][16 rows][32 K] bf16
+    assert n.value == 512 + 4 * 32 * 320 * 2 + 8 * 5 * 16 * 32 * 2
+    d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128, stride_h=2, stride_w=2)      # stride 2: generic layout only
+    assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
     assert n.value == 512 + 4 * 32 * 320 * 2
     # depthwise goes through its own entry point
     d = _desc(Cin=144, Cout=144, groups=144, x_cpitch=144)
