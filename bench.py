@@ -33,6 +33,7 @@ WORKLOADS = {
     "mobilenetv3_large_w1_bs512": ("mobilenetv3_large_w1", 512, "depthwise", "hbm"),
     "efficientnet_b0_bs256": ("efficientnet_b0", 256, "depthwise", "hbm"),
     "vgg16_bs128": ("vgg16", 128, "dense3x3", "mfma"),
+    "seresnet50_bs256": ("seresnet50", 256, "dense3x3", "mfma"),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"
@@ -71,12 +72,12 @@ class LaunchTimer(object):
         timer = self
         self._orig = engine.ConvRunner._launch
 
-        def timed(runner, x, d, residual, out=None):
+        def timed(runner, x, d, residual, out=None, gate=None):
             if out is not None or timer.classify(runner, d) != timer.klass:
-                return timer._orig(runner, x, d, residual, out)
+                return timer._orig(runner, x, d, residual, out, gate)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            y = timer._orig(runner, x, d, residual)
+            y = timer._orig(runner, x, d, residual, None, gate)
             e.record()
             es = x.t.element_size()
             cin_g = d.Cin // d.groups

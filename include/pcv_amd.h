@@ -124,6 +124,16 @@ int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const 
  * [N, Hq, Wq, Cout] (Hq = (Ho + 2 - 3) / 2 + 1), the full-resolution convolution output is never written. Results are
  * bit-identical to pcv_conv2d_fused followed by pcv_maxpool2d. `pcv_conv2d_maxpool_supported` tells whether a descriptor and
  * pooling geometry are covered (the caller otherwise issues the two launches). */
+/* pcv_conv2d_fused with a per-image channel gate: y = post_act(act(scale * conv + shift) * gate[n, c] + residual), gate fp32
+ * [N][Cout]. This is how an SE block behind a LINEAR convolution runs in one pass (seresnet.py:60-71: body.conv3 has no
+ * activation, so mean_hw(BN(conv3(z))) = BN(conv3(mean_hw(z))): the squeeze is taken on the 4x narrower input z, the excitation
+ * runs before the convolution, and the scale + skip add + ReLU ride in its epilogue - the SE block's own two passes over the
+ * wide tensor disappear). `pcv_fc_f32` is the small fp32 dense layer out[N,J] = act(b + in[N,K] . w[J,K]^T) that maps the
+ * squeezed input through the (BN-folded) convolution. */
+int pcv_conv2d_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                           const float* shift, const float* gate, const void* residual, void* y, void* stream);
+int pcv_fc_f32(pcv_ctx* ctx, const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act,
+               void* stream);
 int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, int ceil_mode);
 int pcv_conv2d_maxpool_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
                              const float* shift, void* y, int k, int s, int p, int ceil_mode, void* stream);

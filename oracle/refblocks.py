@@ -15,7 +15,7 @@ __all__ = ['block_forward']
 
 import torch
 import torch.nn.functional as F
-from .refnet import (Quant, conv_block, se_block, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit, bn_act,
+from .refnet import (Quant, conv_block, se_block, conv_then_se, _res_body, tf_same_pad, effi_dws_unit, effi_inv_res_unit, bn_act,
                      pre_conv_chain, preres_unit, preres_init_block, dense_unit, dense_transition, shuffle_unit)
 
 _KSIZE = {"conv1x1_block": (1, 0), "conv3x3_block": (3, 1), "conv5x5_block": (5, 2), "conv7x7_block": (7, 3),
@@ -104,6 +104,10 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
             stride = kw.get("stride", 1)
             resize = (kw["in_channels"] != kw["out_channels"]) or (stride != 1)
             identity = conv_block(sd, "identity_conv.", x, stride=stride, act=None, q=q) if resize else x
+            if kind == "SEResUnit" and kw["bottleneck"]:
+                y = conv_block(sd, "body.conv1.", x, stride=(stride if kw["conv1_stride"] else 1), q=q)
+                y = conv_block(sd, "body.conv2.", y, stride=(1 if kw["conv1_stride"] else stride), padding=1, q=q)
+                return conv_then_se(sd, "body.conv3.", "se.", y, q, identity, "relu")
             if kind == "SEResUnit":
                 y = _res_body(sd, "body.", x, stride, kw["bottleneck"], kw["conv1_stride"], q, None, None)
                 return se_block(sd, "se.", y, q=q, residual=identity, post_act="relu")

@@ -22,7 +22,7 @@
 """
 
 __all__ = ['Quant', 'conv_block', 'se_block', 'resnet_forward', 'mobilenetv2_forward', 'resnext_forward',
-           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'shufflenetv2_forward', 'vgg_forward', 'shuffle_unit', 'channel_shuffle', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn']
+           'seresnet_forward', 'seresnext_forward', 'mobilenet_forward', 'mobilenetv3_forward', 'efficientnet_forward', 'preresnet_forward', 'densenet_forward', 'shufflenetv2_forward', 'vgg_forward', 'shuffle_unit', 'channel_shuffle', 'dense_unit', 'dense_transition', 'bn_act', 'pre_conv_chain', 'preres_unit', 'preres_init_block', 'tf_same_pad', 'effi_dws_unit', 'effi_inv_res_unit', 'forward', 'MODEL_ARCH', 'fold_bn', 'conv_then_se']
 
 import math
 import torch
@@ -134,6 +134,31 @@ def se_block(sd: dict, prefix: str, x: torch.Tensor, q: Quant | None = None,
     return q.r(y)
 
 
+def conv_then_se(sd, conv_p, se_p, z, q, residual, post_act, eps=1e-5):
+    """conv_block(act=None) -> SEBlock -> (+ residual) -> post_act (seresnet.py:63-72, seresnext.py:65-76). In fp32 this is the
+    reference's arithmetic. In a 16-bit mode it follows the ROUNDING POINTS of the GPU pipeline, which runs the SE block inside
+    the 1x1 convolution's launch (SEBlock.run_behind): BN(conv(.)) is affine, so the squeeze is BN(conv(mean_hw(z))) (fp32
+    weights), the excitation runs first, and the convolution's unrounded fp32 result is scaled, added to the skip tensor,
+    activated and only then rounded."""
+    q = q or Quant(None)
+    if not q.on:
+        y = conv_block(sd, conv_p, z, act=None, q=q)
+        return se_block(sd, se_p, y, q=q, residual=residual, post_act=post_act)
+    w = sd[conv_p + "conv.weight"].float()
+    scale, shift = fold_bn(sd, conv_p + "bn.", eps)
+    bias = sd.get(conv_p + "conv.bias", None)
+    if bias is not None:
+        shift = shift + bias.float() * scale
+    sq = F.conv2d(z.mean(dim=(2, 3), keepdim=True), w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    g = F.conv2d(sq, sd[se_p + "conv1.weight"], sd[se_p + "conv1.bias"])
+    g = torch.sigmoid(F.conv2d(F.relu(g), sd[se_p + "conv2.weight"], sd[se_p + "conv2.bias"]))
+    y = F.conv2d(z, q.r(w)) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = y * g
+    if residual is not None:
+        y = y + residual
+    return q.r(_act(y, post_act))
+
+
 def _tap(taps, name, t):
     if taps is not None:
         taps[name] = t
@@ -203,7 +228,11 @@ def resnet_forward(sd, x, blocks, bottleneck=None, conv1_stride=True, q=None, ta
                 identity = conv_block(sd, p + "identity_conv.", x, stride=stride, act=None, q=q)
             else:
                 identity = x
-            if se:
+            if se and bottleneck:
+                y = conv_block(sd, p + "body.conv1.", x, stride=(stride if conv1_stride else 1), q=q)
+                y = conv_block(sd, p + "body.conv2.", y, stride=(1 if conv1_stride else stride), padding=1, q=q)
+                x = conv_then_se(sd, p + "body.conv3.", p + "se.", y, q, identity, "relu")
+            elif se:
                 y = _res_body(sd, p + "body.", x, stride, bottleneck, conv1_stride, q, None, None)
                 x = se_block(sd, p + "se.", y, q=q, residual=identity, post_act="relu")
             else:
@@ -262,8 +291,7 @@ def seresnext_forward(sd, x, blocks, cardinality, bottleneck_width, q=None, taps
                 identity = x
             y = conv_block(sd, p + "body.conv1.", x, q=q)
             y = conv_block(sd, p + "body.conv2.", y, stride=stride, padding=1, groups=cardinality, q=q)
-            y = conv_block(sd, p + "body.conv3.", y, act=None, q=q)
-            x = se_block(sd, p + "se.", y, q=q, residual=identity, post_act="relu")
+            x = conv_then_se(sd, p + "body.conv3.", p + "se.", y, q, identity, "relu")
             in_ch = out_ch
         _tap(taps, "stage{}".format(i + 1), x)
     return _classifier(sd, x, q)

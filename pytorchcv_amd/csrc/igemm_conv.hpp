@@ -61,6 +61,8 @@ struct IgemmParams {
     int ksteps_per_tap;     // KHW == 9: K-steps per filter tap (= cin_blk / elements per K-step)
     int korder;             // KHW == 9: 0 = K ordered (r, q, slice), 1 = (r, slice, q)
     int wstat;              // weight-stationary persistent mode (nk == 1, one channel tile, one group-block)
+    const float* gate;      // [N][Cout_total] fp32 or null: per-image channel gate applied between the activation and the residual
+                            // add (SE blocks whose squeeze was taken upstream of this convolution, pcv_conv2d_gated_fused)
 };
 
 template <int DT> struct Mma;
@@ -388,6 +390,19 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                     v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
                 }
                 apply_act8(v, act);
+                if (p.gate != nullptr) {
+                    const uint32_t n = fastdiv((uint32_t)(m < p.M ? m : 0), p.div_howo);
+                    const float* gp = p.gate + (size_t)n * p.Cout_total + chg;
+                    if constexpr (RAGGED) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (ch0 + e < p.Cout) v[e] *= gp[e];
+                    } else if (ch0 < p.Cout) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                    }
+                }
                 if (p.res != nullptr) {
                     if constexpr (RAGGED) {
 #pragma unroll

@@ -816,10 +816,11 @@ int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, cons
 
 // ---- hot path ----------------------------------------------------------------------------------------------
 static int pool_out(int in, int k, int s, int p, int ceil_mode);
+static void launch_se_fc(const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act, hipStream_t st);
 
 // pool: the MaxPool2d(3, 2, 1) of the init block fused behind the stem convolution (pcv_conv2d_maxpool_fused)
 static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
-                       const float* shift, const void* residual, void* y, void* stream, bool pool) {
+                       const float* shift, const void* residual, void* y, void* stream, bool pool, const float* gate = nullptr) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
     if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
@@ -843,6 +844,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
 
     const bool sliced_y = d->y_cpitch > 0 && d->y_cpitch != d->Cout;
     if (P.stem && sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
+    if (gate && (P.stem || pool)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: the stem kernel has no gate");
     if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
     if (P.stem) {
         StemParams q;
@@ -876,7 +878,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return PCV_OK;
     }
 
-    if (P.gconv && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && d->W <= 63 && cpitch == d->Cin &&
+    if (P.gconv && !gate && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && d->W <= 63 && cpitch == d->Cin &&
         wpitch == d->W && M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull) {
         GConvParams q;
         std::memset(&q, 0, sizeof(q));
@@ -901,7 +903,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
-    if (P.conv3 && ctx->use_c64 && !sliced_y && d->Cin == 64 && d->Cout == 64 && d->W <= 63 && d->dtype != PCV_F32 &&
+    if (P.conv3 && !gate && ctx->use_c64 && !sliced_y && d->Cin == 64 && d->Cout == 64 && d->W <= 63 && d->dtype != PCV_F32 &&
         (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * 64ull * 2ull < 0x80000000ull && P.Kpad == 576) {
         HConvParams q;
         std::memset(&q, 0, sizeof(q));
@@ -933,7 +935,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
-    if (P.conv3 && ctx->use_hconv && !sliced_y && d->W <= 63 && d->Cout % 8 == 0 && d->out_dtype == d->dtype &&
+    if (P.conv3 && !gate && ctx->use_hconv && !sliced_y && d->W <= 63 && d->Cout % 8 == 0 && d->out_dtype == d->dtype &&
         (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * (unsigned long long)d->Cout * P.ES < 0x80000000ull) {
         HConvParams q;
         q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
@@ -959,7 +961,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
-    bool take_conv3 = P.conv3 && ctx->use_conv3 && !sliced_y;
+    bool take_conv3 = P.conv3 && !gate && ctx->use_conv3 && !sliced_y;
     if (take_conv3 && ctx->force_conv3_cfg < 0) {
         const int c3 = d->Cout <= 64 ? C3_64x512 : C3_128x256;
         const long long tiles = ((long long)((M64 + kConv3[c3].BP - 1) / kConv3[c3].BP)) * ((d->Cout + kConv3[c3].BM - 1) / kConv3[c3].BM);
@@ -1025,6 +1027,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.ktab = reinterpret_cast<const uint32_t*>(packed);
     p.w = static_cast<const char*>(packed) + P.ktab_bytes;
     p.res = d->has_residual ? residual : nullptr;
+    p.gate = gate;
     p.y = y;
     p.scale = scale;
     p.shift = shift;
@@ -1092,6 +1095,24 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
 int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
                      const float* shift, const void* residual, void* y, void* stream) {
     return conv2d_impl(ctx, d, x, packed, scale, shift, residual, y, stream, false);
+}
+
+int pcv_conv2d_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                           const float* shift, const float* gate, const void* residual, void* y, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!gate || !aligned16(gate)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: gate must be a 16-byte aligned [N][Cout] fp32 array");
+    if (d && d->Cout % 4 != 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: Cout must be a multiple of 4");
+    return conv2d_impl(ctx, d, x, packed, scale, shift, residual, y, stream, false, gate);
+}
+
+int pcv_fc_f32(pcv_ctx* ctx, const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act,
+               void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!in || !w || !b || !out || N <= 0 || K <= 0 || J <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_fc_f32: bad argument");
+    launch_se_fc(in, w, b, out, N, K, J, act, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
 }
 
 int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, int ceil_mode) {

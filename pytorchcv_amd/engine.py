@@ -268,7 +268,7 @@ class ConvRunner(object):
         torch.cuda.current_stream(dev).synchronize()      # w32 & friends are temporaries; load-time only
         self.packed, self.scale, self.shift, self._key = packed, scale, shift, key
 
-    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None, out=None) -> NHWC:
+    def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None, out=None, gate=None) -> NHWC:
         """`pad4`: explicit (left, right, top, bottom) zero padding for this call (the `F.pad` a unit applies in front of
         a padding-0 convolution, efficientnet.py:108-109,189-190,236-237); it stays inside the kernel's bounds checks."""
         if pad4 is not None:
@@ -277,7 +277,7 @@ class ConvRunner(object):
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
         d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None, logits=out_fp32)
         self.prepare(x, d)
-        return self._launch(x, d, residual, out)
+        return self._launch(x, d, residual, out, gate)
 
     def run_maxpool(self, x: NHWC, act: int, k: int, s: int, p: int, ceil_mode: bool = False):
         """This convolution + BN + activation and the MaxPool2d(k, s, p) behind it as ONE launch when covered
@@ -355,7 +355,7 @@ class ConvRunner(object):
                                                    _ptr(nxt.shift), _ptr(t2), st), ctx)
         return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels, cpitch=d2.Cout)
 
-    def _launch(self, x: NHWC, d: ConvDesc, residual, out=None):
+    def _launch(self, x: NHWC, d: ConvDesc, residual, out=None, gate=None):
         """`out` = (tensor [N, Ho, Wo, Ctot], channel offset): write the result into that channel slice of a wider
         (concatenation) buffer instead of a fresh tensor - `torch.cat((identity, x), dim=1)` without the copy."""
         c = self.conv
@@ -378,22 +378,61 @@ class ConvRunner(object):
             if not residual.dense or tuple(residual.t.shape) != (x.N, Ho, Wo, d.Cout) or residual.dtype != x.dtype:
                 raise RuntimeError("residual shape/dtype mismatch: {} vs {}".format(
                     tuple(residual.t.shape), (x.N, Ho, Wo, d.Cout)))
-        self._launch_range(x, d, residual, y, 0, x.N)
+        if gate is not None:
+            if self.depthwise or gate.dtype != torch.float32 or tuple(gate.shape) != (x.N, d.Cout) or not gate.is_contiguous():
+                raise RuntimeError("gate must be a contiguous fp32 [N, {}] tensor of a dense convolution".format(d.Cout))
+        self._launch_range(x, d, residual, y, 0, x.N, gate)
         return None if out is not None else NHWC(y, x.N, Ho, Wo, c.out_channels, cpitch=d.Cout)
 
-    def _launch_range(self, x, d, residual, y, n0, n1):
+    def _launch_range(self, x, d, residual, y, n0, n1, gate=None):
         """Launch images [n0, n1); halve the range when one launch would exceed the 2 GiB addressing window."""
         L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
         d.N = n1 - n0
-        fn = L.pcv_dwconv2d_fused if self.depthwise else L.pcv_conv2d_fused
-        rc = fn(ctx, ctypes.byref(d), _ptr(x.t[n0:n1]), _ptr(self.packed), _ptr(self.scale), _ptr(self.shift),
-                _ptr(residual.t[n0:n1]) if residual is not None else None, _ptr(y[n0:n1]), st)
+        rp = _ptr(residual.t[n0:n1]) if residual is not None else None
+        if gate is not None:
+            rc = L.pcv_conv2d_gated_fused(ctx, ctypes.byref(d), _ptr(x.t[n0:n1]), _ptr(self.packed), _ptr(self.scale),
+                                          _ptr(self.shift), _ptr(gate[n0:n1]), rp, _ptr(y[n0:n1]), st)
+        else:
+            fn = L.pcv_dwconv2d_fused if self.depthwise else L.pcv_conv2d_fused
+            rc = fn(ctx, ctypes.byref(d), _ptr(x.t[n0:n1]), _ptr(self.packed), _ptr(self.scale), _ptr(self.shift), rp, _ptr(y[n0:n1]), st)
         if rc == _lib.PCV_ERR_TOO_LARGE and n1 - n0 > 1:
             mid = (n0 + n1) // 2
-            self._launch_range(x, d, residual, y, n0, mid)
-            self._launch_range(x, d, residual, y, mid, n1)
+            self._launch_range(x, d, residual, y, n0, mid, gate)
+            self._launch_range(x, d, residual, y, mid, n1, gate)
             return
         _lib.check(rc, ctx)
+
+    def squeezed_excite(self, z: NHWC, w1, b1, w2, b2, mid_act: int, out_act: int) -> torch.Tensor:
+        """SE gate of `SEBlock(BN(conv(z)))` for a 1x1 stride-1 convolution WITHOUT activation, computed before the convolution
+        runs: mean_hw(BN(conv(z))) = BN(conv(mean_hw(z))) (both affine), and the first excitation layer absorbs that map:
+        mid = mid_act(W1 . (S W mean + shift) + b1) = mid_act((W1 S W) . mean + (W1 shift + b1)) with the [M, Cin] product
+        folded once at load time. Two small fp32 layers on the squeezed INPUT: gate fp32 [N, Cout_physical]."""
+        c = self.conv
+        if self.depthwise or c.groups != 1 or tuple(_pair(c.kernel_size)) != (1, 1) or tuple(_pair(c.stride)) != (1, 1) or \
+                self.pad4 is not None or tuple(_pair(c.padding)) != (0, 0):
+            raise RuntimeError("squeezed_excite needs a plain 1x1 stride-1 convolution")
+        d = self.desc(z, 0, 0, False)
+        self.prepare(z, d)                                   # scale / shift of the folded BatchNorm (+ bias)
+        key = ("sq", self._key, w1.data_ptr(), w2.data_ptr(), w1._version, w2._version, b1._version, b2._version)
+        if getattr(self, "_sq_key", None) != key:
+            Cl, CP = c.out_channels, d.Cout
+            w = c.weight.detach().float().reshape(Cl, -1)
+            w = F.pad(w, (0, d.Cin - w.shape[1], 0, CP - Cl)) * self.scale[:, None]       # [CP, Cin]: BN scale folded into the rows
+            w1p = F.pad(w1.float(), (0, CP - Cl))                                          # [M, CP]
+            self._sq_w1 = (w1p @ w).contiguous()                                           # [M, Cin]
+            self._sq_b1 = (w1p @ self.shift + b1.float()).contiguous()
+            self._sq_w2 = F.pad(w2.float(), (0, 0, 0, CP - Cl)).contiguous()               # [CP, M]
+            self._sq_b2 = F.pad(b2.float(), (0, CP - Cl)).contiguous()
+            self._sq_key = key
+        L, ctx, st = _lib.lib(), _ctx(z.device), _stream(z.device)
+        M = self._sq_w1.shape[0]
+        mean = torch.empty((z.N, d.Cin), dtype=torch.float32, device=z.device)
+        _lib.check(L.pcv_se_squeeze(ctx, _ptr(z.t), _ptr(mean), z.N, z.H * z.W, d.Cin, _CODE_OF_TORCH[z.dtype], st), ctx)
+        mid = torch.empty((z.N, M), dtype=torch.float32, device=z.device)
+        gate = torch.empty((z.N, d.Cout), dtype=torch.float32, device=z.device)
+        _lib.check(L.pcv_fc_f32(ctx, _ptr(mean), _ptr(self._sq_w1), _ptr(self._sq_b1), _ptr(mid), z.N, d.Cin, M, mid_act, st), ctx)
+        _lib.check(L.pcv_fc_f32(ctx, _ptr(mid), _ptr(self._sq_w2), _ptr(self._sq_b2), _ptr(gate), z.N, M, d.Cout, out_act, st), ctx)
+        return gate
 
 
 def _pool_out(n: int, k: int, s: int, p: int, ceil_mode: bool) -> int:

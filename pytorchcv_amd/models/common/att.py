@@ -45,6 +45,25 @@ class SEBlock(nn.Module):
         w2 = b.weight.detach().float().reshape(b.weight.shape[0], -1).contiguous()
         return w1, a.bias.detach().float().contiguous(), w2, b.bias.detach().float().contiguous()
 
+    def run_behind(self, conv_block, z, residual=None, post_act=None):
+        """`self(conv_block(z), residual, post_act)` in ONE pass over the wide tensor when `conv_block` is a plain 1x1 ConvBlock
+        without activation (the bottleneck's last convolution, seresnet.py:60-71): BN(conv(.)) is affine, so the squeeze
+        mean_hw(BN(conv(z))) = BN(conv(mean_hw(z))) is taken on the narrower input z, the excitation runs BEFORE the convolution
+        and the channel scale + skip add + activation ride in its epilogue (pcv_conv2d_gated_fused). Returns None when the block
+        is not of that shape (the caller then runs conv_block and this module one after the other)."""
+        from .conv import ConvBlock
+        c = getattr(conv_block, "conv", None)
+        if not (engine.FUSE_UNITS and isinstance(conv_block, ConvBlock) and isinstance(z, engine.NHWC) and not conv_block.activate and
+                not conv_block.use_pad and c is not None and tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) and
+                tuple(c.padding) == (0, 0) and c.groups == 1 and z.dense):
+            return None
+        if conv_block._pcv_runner is None:
+            conv_block._pcv_runner = engine.ConvRunner(conv_block.conv, conv_block.bn if conv_block.normalize else None)
+        runner = conv_block._pcv_runner
+        w1, b1, w2, b2 = self._mlp()
+        gate = runner.squeezed_excite(z, w1, b1, w2, b2, engine.act_code(self.activ), engine.act_code(self.sigmoid))
+        return runner.run(z, act=0, residual=residual, post_act=engine.act_code(post_act), gate=gate)
+
     def forward(self, x, residual=None, post_act=None):
         w1, b1, w2, b2 = self._mlp()
         return engine.boundary(self, x, lambda a: engine.se_forward(

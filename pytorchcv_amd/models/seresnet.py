@@ -31,7 +31,13 @@ class SEResUnit(nn.Module):
 
     def _run(self, a):
         identity = self.identity_conv(a) if self.resize_identity else a
-        return self.se(self.body(a), residual=identity, post_act=self.activ)
+        body = self.body
+        if hasattr(body, "conv3"):
+            # bottleneck: the SE block runs inside conv3's launch (squeeze taken on conv3's input, SEBlock.run_behind)
+            z = body.conv2(body.conv1(a))
+            y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ)
+            return y if y is not None else self.se(body.conv3(z), residual=identity, post_act=self.activ)
+        return self.se(body(a), residual=identity, post_act=self.activ)
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)

@@ -28,7 +28,10 @@ class SEResNeXtUnit(nn.Module):
 
     def _run(self, a):
         identity = self.identity_conv(a) if self.resize_identity else a
-        return self.se(self.body(a), residual=identity, post_act=self.activ)
+        body = self.body
+        z = body.conv2(body.conv1(a))
+        y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ)      # SE inside conv3's launch
+        return y if y is not None else self.se(body.conv3(z), residual=identity, post_act=self.activ)
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)
