@@ -183,6 +183,14 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
                            const void* packed1, const float* scale1, const float* shift1, const void* residual, void* y1,
                            const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
 
+/* The pair with pcv_conv2d_gated_fused's per-image channel gate on the first convolution (an SE block run inside it:
+ * y1 = post_act(act(BN(conv1(x))) * gate[n, c] + residual)); covered for the LDS-ring kernels (first convolution 128 or 256 in). */
+int pcv_conv1x1_pair_gated_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2);
+int pcv_conv1x1_pair_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
+                                 const void* packed1, const float* scale1, const float* shift1, const float* gate,
+                                 const void* residual, void* y1, const void* packed2, const float* scale2, const float* shift2,
+                                 void* y2, void* stream);
+
 /* The same pair when the unit's skip tensor is itself a 1x1 convolution + BN of the unit's input x0 (first unit of a stage,
  * `identity_conv`, resnet.py:214-216,225-226): the kernel recomputes the skip tile from x0 instead of reading it, so the
  * identity convolution's own launch and both passes over its 4x wider output disappear. `d_id` describes the identity

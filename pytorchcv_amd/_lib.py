@@ -63,6 +63,9 @@ _SIGS = {
     "pcv_conv1x1_pair_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "pcv_conv1x1_pair_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                     _VP, _VP, _VP, _VP]),
+    "pcv_conv1x1_pair_gated_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
+    "pcv_conv1x1_pair_gated_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                          _VP, _VP, _VP, _VP, _VP]),
     "pcv_conv1x1_pair_idconv_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "pcv_conv1x1_pair_idconv_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc),
                                            _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                 }
                 apply_act8(v, act);
                 if (p.gate != nullptr) {
+#pragma clang fp contract(off)      // the product is rounded before the skip add here and in wpair1x1.hpp alike (bit-identical paths)
                     const uint32_t n = fastdiv((uint32_t)(m < p.M ? m : 0), p.div_howo);
                     const float* gp = p.gate + (size_t)n * p.Cout_total + chg;
                     if constexpr (RAGGED) {

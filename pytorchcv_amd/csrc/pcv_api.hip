@@ -424,18 +424,21 @@ static int g_wpair_mask = 3;                                                    
 static int g_wpair_blocks_per_cu[4] = {1, 1, 1, 1};
 // wide pair configurations: 0: 128 -> 512, 1: 256 -> 1024 (ResNet), 2: 128 -> 256, 3: 256 -> 512 (ResNeXt 32x4d)
 struct WPairLaunch { const void* fn; int threads, lds, tileP; };
-template <int CM, int C1> static WPairLaunch wpair_launch_for(int dt) {
+template <int CM, int C1> static WPairLaunch wpair_launch_for(int dt, bool gated) {
     typedef WPairCfg<CM, C1> G;
-    const void* fn = dt == PCV_BF16 ? reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, CM, C1>)
-                                    : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1>);
+    const void* fn;
+    if (gated) fn = dt == PCV_BF16 ? reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, CM, C1, true>)
+                                   : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1, true>);
+    else fn = dt == PCV_BF16 ? reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, CM, C1, false>)
+                             : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1, false>);
     return WPairLaunch{fn, 64 * G::NW, G::LDS, G::P};
 }
-static WPairLaunch wpair_launch(int cfg, int dt) {
+static WPairLaunch wpair_launch(int cfg, int dt, bool gated = false) {
     switch (cfg) {
-        case 0: return wpair_launch_for<128, 512>(dt);
-        case 1: return wpair_launch_for<256, 1024>(dt);
-        case 2: return wpair_launch_for<128, 256>(dt);
-        default: return wpair_launch_for<256, 512>(dt);
+        case 0: return wpair_launch_for<128, 512>(dt, gated);
+        case 1: return wpair_launch_for<256, 1024>(dt, gated);
+        case 2: return wpair_launch_for<128, 256>(dt, gated);
+        default: return wpair_launch_for<256, 512>(dt, gated);
     }
 }
 static int wpair_cfg(int cm, int c1) {
@@ -469,6 +472,7 @@ static int enable_pair(pcv_ctx* ctx) {
         for (int dt = PCV_BF16; dt <= PCV_F16; ++dt) {
             const WPairLaunch L = wpair_launch(cfg, dt);
             HIP_TRY(ctx, hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+            HIP_TRY(ctx, hipFuncSetAttribute(wpair_launch(cfg, dt, true).fn, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
             int nb = 0;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, L.fn, L.threads, L.lds));
             g_wpair_blocks_per_cu[cfg] = nb < 1 ? 1 : nb;
@@ -1310,9 +1314,33 @@ int pcv_conv1x1_pair_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2)
     return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr) ? 1 : 0;
 }
 
+static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x, const void* packed1,
+                     const float* scale1, const float* shift1, const float* gate, const void* residual, void* y1,
+                     const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
+
 int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x, const void* packed1,
                            const float* scale1, const float* shift1, const void* residual, void* y1, const void* packed2,
                            const float* scale2, const float* shift2, void* y2, void* stream) {
+    return pair_impl(ctx, d1, d2, x, packed1, scale1, shift1, nullptr, residual, y1, packed2, scale2, shift2, y2, stream);
+}
+
+int pcv_conv1x1_pair_gated_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2) {
+    return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr && d1->Cin >= 128) ? 1 : 0;      // the LDS-ring kernels only
+}
+
+int pcv_conv1x1_pair_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
+                                 const void* packed1, const float* scale1, const float* shift1, const float* gate,
+                                 const void* residual, void* y1, const void* packed2, const float* scale2, const float* shift2,
+                                 void* y2, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!gate || !aligned16(gate) || !pcv_conv1x1_pair_gated_supported(d1, d2))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_gated_fused: unsupported pair or missing gate");
+    return pair_impl(ctx, d1, d2, x, packed1, scale1, shift1, gate, residual, y1, packed2, scale2, shift2, y2, stream);
+}
+
+static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x, const void* packed1,
+                     const float* scale1, const float* shift1, const float* gate, const void* residual, void* y1,
+                     const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
     if (!d1 || !d2 || !x || !packed1 || !scale1 || !shift1 || !residual || !y1 || !packed2 || !scale2 || !shift2 || !y2)
@@ -1338,7 +1366,9 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
         q.x_bytes = q.y2_bytes = (uint32_t)(M * CM * 2); q.res_bytes = q.y1_bytes = (uint32_t)(M * C1 * 2);
         q.w1_bytes = q.w2_bytes = (uint32_t)(C1 * CM * 2);
-        const WPairLaunch L = wpair_launch(cfg, d1->dtype);
+        const WPairLaunch L = wpair_launch(cfg, d1->dtype, gate != nullptr);
+        q.gate = gate;
+        q.div_hw = make_fastdiv((uint32_t)(d1->H * d1->W));
         q.M = (int)M; q.nTiles = (int)((M + L.tileP - 1) / L.tileP);
         q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
         const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[cfg]);
@@ -1346,6 +1376,7 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
         HIP_TRY(ctx, hipLaunchKernel(L.fn, dim3(grid), dim3((unsigned)L.threads), args, (size_t)L.lds, st));
         return PCV_OK;
     }
+    if (gate) return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_gated_fused: the register-resident 64 -> 256 pair has no gate");
     if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || P1.ngb != 1 || P2.ngb != 1)
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
     PairParams p;

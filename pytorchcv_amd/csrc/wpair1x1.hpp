@@ -44,6 +44,10 @@ struct WPairParams {
     uint32_t x_bytes, res_bytes, y1_bytes, y2_bytes, w1_bytes, w2_bytes;
     int M, nTiles;
     int act1, post1, act2;
+    // GATE: y1 = post1(act1(BN(acc)) * gate[n, c] + res), gate fp32 [N][C1] (an SE block run inside the first convolution,
+    // pcv_conv2d_gated_fused's epilogue); n = pixel / HW
+    const float* gate;
+    FastDiv div_hw;
 };
 
 template <int N> __device__ __forceinline__ void wpair_wait_vmcnt() {
@@ -69,7 +73,7 @@ template <int CM, int C1_ = 4 * CM> struct WPairCfg {
     static constexpr int LDS = TAB + (2 * C1 + 2 * CM) * 4;
 };
 
-template <int DT, int CM, int C1_ = 4 * CM>
+template <int DT, int CM, int C1_ = 4 * CM, bool GATE = false>
 __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kernel(const WPairParams p) {   // 2 waves per SIMD: 256 registers
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef WPairCfg<CM, C1_> G;
@@ -241,6 +245,15 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
                         v[4 + e] = acc1[2 * ipl + 1][j][e] * s1[e] + h1[e];
                     }
                     apply_act8(v, act1);
+                    if constexpr (GATE) {
+#pragma clang fp contract(off)      // as in igemm_conv.hpp: the product is rounded before the skip add
+                        const long pix = pix_of(tile, j);
+                        const uint32_t n = fastdiv((uint32_t)(pix < p.M ? pix : p.M - 1), p.div_hw);
+                        const float* gp = p.gate + (size_t)n * C1 + ch;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) unpack2<DT>(resr[par][ipl][j][e], r8[2 * e], r8[2 * e + 1]);
 #pragma unroll

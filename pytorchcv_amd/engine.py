@@ -301,7 +301,7 @@ class ConvRunner(object):
                                               _ptr(y), k, s, p, 1 if ceil_mode else 0, _stream(x.device)), ctx)
         return NHWC(y, x.N, Hq, Wq, self.conv.out_channels, cpitch=d.Cout)
 
-    def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):
+    def run_pair(self, x: NHWC, residual: NHWC, act: int, post_act: int, nxt: "ConvRunner", nxt_act: int, gate=None):
         """This convolution (+ residual, + post_act) and the 1x1 convolution `nxt` that consumes its output, as ONE launch
         (pcv_conv1x1_pair_fused): returns (y1, y2), or None when the pair of shapes is not covered by the fused kernel."""
         if not FUSE_UNITS or residual is None or self.depthwise or nxt.depthwise or self.pad4 is not None or nxt.pad4 is not None:
@@ -312,18 +312,26 @@ class ConvRunner(object):
         L, ctx, st = _lib.lib(), _ctx(x.device), _stream(x.device)
         d1 = self.desc(x, act, post_act, True)
         d2 = nxt.desc(_ShapeOnly(x.N, x.H, x.W, c.out_channels, x.dtype), nxt_act, 0, False)
-        if not L.pcv_conv1x1_pair_supported(ctypes.byref(d1), ctypes.byref(d2)):
+        supported = L.pcv_conv1x1_pair_gated_supported if gate is not None else L.pcv_conv1x1_pair_supported
+        if not supported(ctypes.byref(d1), ctypes.byref(d2)):
             return None
         if not residual.dense or residual.dtype != x.dtype or tuple(residual.t.shape) != (x.N, x.H, x.W, d1.Cout):
             raise RuntimeError("residual shape/dtype mismatch")
+        if gate is not None and (gate.dtype != torch.float32 or tuple(gate.shape) != (x.N, d1.Cout) or not gate.is_contiguous()):
+            raise RuntimeError("gate must be a contiguous fp32 [N, {}] tensor".format(d1.Cout))
         t1 = torch.empty((x.N, x.H, x.W, d1.Cout), dtype=x.dtype, device=x.device)
         t2 = torch.empty((x.N, x.H, x.W, d2.Cout), dtype=x.dtype, device=x.device)
         y1 = NHWC(t1, x.N, x.H, x.W, c.out_channels, cpitch=d1.Cout)
         self.prepare(x, d1)
         nxt.prepare(y1, d2)
-        _lib.check(L.pcv_conv1x1_pair_fused(ctx, ctypes.byref(d1), ctypes.byref(d2), _ptr(x.t), _ptr(self.packed),
-                                            _ptr(self.scale), _ptr(self.shift), _ptr(residual.t), _ptr(t1), _ptr(nxt.packed),
-                                            _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
+        if gate is not None:
+            _lib.check(L.pcv_conv1x1_pair_gated_fused(ctx, ctypes.byref(d1), ctypes.byref(d2), _ptr(x.t), _ptr(self.packed),
+                                                      _ptr(self.scale), _ptr(self.shift), _ptr(gate), _ptr(residual.t), _ptr(t1),
+                                                      _ptr(nxt.packed), _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
+        else:
+            _lib.check(L.pcv_conv1x1_pair_fused(ctx, ctypes.byref(d1), ctypes.byref(d2), _ptr(x.t), _ptr(self.packed),
+                                                _ptr(self.scale), _ptr(self.shift), _ptr(residual.t), _ptr(t1), _ptr(nxt.packed),
+                                                _ptr(nxt.scale), _ptr(nxt.shift), _ptr(t2), st), ctx)
         return y1, NHWC(t2, x.N, x.H, x.W, nxt.conv.out_channels, cpitch=d2.Cout)
 
     def run_pair_idconv(self, x: NHWC, x0: NHWC, idr: "ConvRunner", act: int, post_act: int, nxt: "ConvRunner", nxt_act: int):

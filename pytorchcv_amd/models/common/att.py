@@ -45,12 +45,13 @@ class SEBlock(nn.Module):
         w2 = b.weight.detach().float().reshape(b.weight.shape[0], -1).contiguous()
         return w1, a.bias.detach().float().contiguous(), w2, b.bias.detach().float().contiguous()
 
-    def run_behind(self, conv_block, z, residual=None, post_act=None):
+    def run_behind(self, conv_block, z, residual=None, post_act=None, next_conv=None):
         """`self(conv_block(z), residual, post_act)` in ONE pass over the wide tensor when `conv_block` is a plain 1x1 ConvBlock
         without activation (the bottleneck's last convolution, seresnet.py:60-71): BN(conv(.)) is affine, so the squeeze
         mean_hw(BN(conv(z))) = BN(conv(mean_hw(z))) is taken on the narrower input z, the excitation runs BEFORE the convolution
         and the channel scale + skip add + activation ride in its epilogue (pcv_conv2d_gated_fused). Returns None when the block
-        is not of that shape (the caller then runs conv_block and this module one after the other)."""
+        is not of that shape (the caller then runs conv_block and this module one after the other). With `next_conv` (the next
+        unit's first 1x1 ConvBlock) the result may be the tuple (y, next_conv(y)) of pcv_conv1x1_pair_gated_fused."""
         from .conv import ConvBlock
         c = getattr(conv_block, "conv", None)
         if not (engine.FUSE_UNITS and isinstance(conv_block, ConvBlock) and isinstance(z, engine.NHWC) and not conv_block.activate and
@@ -62,6 +63,14 @@ class SEBlock(nn.Module):
         runner = conv_block._pcv_runner
         w1, b1, w2, b2 = self._mlp()
         gate = runner.squeezed_excite(z, w1, b1, w2, b2, engine.act_code(self.activ), engine.act_code(self.sigmoid))
+        if next_conv is not None and residual is not None and isinstance(next_conv, ConvBlock):
+            # ... and the next unit's first 1x1 in the same launch: returns (y, next conv1 output)
+            if next_conv._pcv_runner is None:
+                next_conv._pcv_runner = engine.ConvRunner(next_conv.conv, next_conv.bn if next_conv.normalize else None, pad4=next_conv._pad4)
+            pair = runner.run_pair(z, residual, 0, engine.act_code(post_act), next_conv._pcv_runner,
+                                   engine.act_code(next_conv.activ) if next_conv.activate else 0, gate=gate)
+            if pair is not None:
+                return pair
         return runner.run(z, act=0, residual=residual, post_act=engine.act_code(post_act), gate=gate)
 
     def forward(self, x, residual=None, post_act=None):

@@ -9,7 +9,7 @@ __all__ = ['SEResNet', 'seresnet10', 'seresnet18', 'seresnet26', 'seresnetbc26b'
 import torch.nn as nn
 from .common.conv import conv1x1_block
 from .common.att import SEBlock
-from .resnet import ResBlock, ResBottleneck, ResInitBlock, resnet_layers
+from .resnet import ResStage, ResBlock, ResBottleneck, ResInitBlock, resnet_layers
 from ._tail import AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
 
@@ -29,15 +29,22 @@ class SEResUnit(nn.Module):
                                                activation=None)
         self.activ = nn.ReLU(inplace=True)
 
-    def _run(self, a):
+    pcv_chainable = True         # ResStage: first convolution handed in, last one (with the SE block) fused forward
+
+    def run_chained(self, a, conv1_out=None, next_unit=None):
         identity = self.identity_conv(a) if self.resize_identity else a
         body = self.body
-        if hasattr(body, "conv3"):
-            # bottleneck: the SE block runs inside conv3's launch (squeeze taken on conv3's input, SEBlock.run_behind)
-            z = body.conv2(body.conv1(a))
-            y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ)
-            return y if y is not None else self.se(body.conv3(z), residual=identity, post_act=self.activ)
-        return self.se(body(a), residual=identity, post_act=self.activ)
+        if not hasattr(body, "conv3"):                           # basic block: the SE block follows a 3x3 (not affine in the mean)
+            return self.se(body(a), residual=identity, post_act=self.activ), None
+        z = body.conv2(conv1_out if conv1_out is not None else body.conv1(a))
+        nxt = next_unit.body.conv1 if (next_unit is not None and hasattr(next_unit.body, "conv3")) else None
+        y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ, next_conv=nxt)
+        if y is None:
+            y = self.se(body.conv3(z), residual=identity, post_act=self.activ)
+        return y if isinstance(y, tuple) else (y, None)
+
+    def _run(self, a):
+        return self.run_chained(a)[0]
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)
@@ -53,7 +60,7 @@ class SEResNet(nn.Module):
         self.features.add_module("init_block", ResInitBlock(in_channels=in_channels, out_channels=init_block_channels))
         in_channels = init_block_channels
         for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
+            stage = ResStage()
             for j, out_channels in enumerate(channels_per_stage):
                 stride = 2 if (j == 0) and (i != 0) else 1
                 stage.add_module("unit{}".format(j + 1), SEResUnit(in_channels=in_channels, out_channels=out_channels,

@@ -8,7 +8,7 @@ __all__ = ['SEResNeXt', 'seresnext50_32x4d', 'seresnext101_32x4d', 'seresnext101
 import torch.nn as nn
 from .common.conv import conv1x1_block
 from .common.att import SEBlock
-from .resnet import ResInitBlock
+from .resnet import ResStage, ResInitBlock
 from .resnext import ResNeXtBottleneck
 from ._tail import AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
 from .. import engine
@@ -26,12 +26,22 @@ class SEResNeXtUnit(nn.Module):
                                                activation=None)
         self.activ = nn.ReLU(inplace=True)
 
-    def _run(self, a):
+    pcv_chainable = True         # ResStage: first convolution handed in, last one (with the SE block) fused forward
+
+    def run_chained(self, a, conv1_out=None, next_unit=None):
         identity = self.identity_conv(a) if self.resize_identity else a
         body = self.body
-        z = body.conv2(body.conv1(a))
-        y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ)      # SE inside conv3's launch
-        return y if y is not None else self.se(body.conv3(z), residual=identity, post_act=self.activ)
+        if not hasattr(body, "conv3"):                           # basic block: the SE block follows a 3x3 (not affine in the mean)
+            return self.se(body(a), residual=identity, post_act=self.activ), None
+        z = body.conv2(conv1_out if conv1_out is not None else body.conv1(a))
+        nxt = next_unit.body.conv1 if (next_unit is not None and hasattr(next_unit.body, "conv3")) else None
+        y = self.se.run_behind(body.conv3, z, residual=identity, post_act=self.activ, next_conv=nxt)
+        if y is None:
+            y = self.se(body.conv3(z), residual=identity, post_act=self.activ)
+        return y if isinstance(y, tuple) else (y, None)
+
+    def _run(self, a):
+        return self.run_chained(a)[0]
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)
@@ -47,7 +57,7 @@ class SEResNeXt(nn.Module):
         self.features.add_module("init_block", ResInitBlock(in_channels=in_channels, out_channels=init_block_channels))
         in_channels = init_block_channels
         for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
+            stage = ResStage()
             for j, out_channels in enumerate(channels_per_stage):
                 stride = 2 if (j == 0) and (i != 0) else 1
                 stage.add_module("unit{}".format(j + 1), SEResNeXtUnit(in_channels=in_channels, out_channels=out_channels,

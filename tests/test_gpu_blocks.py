@@ -393,3 +393,41 @@ def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, groups=groups, q=q)
     d = (y - ref).abs()
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("cm,c1", [(128, 512), (256, 1024), (128, 256)])
+@pytest.mark.parametrize("shape", [(3, 13, 11), (5, 28, 28), (9, 14, 14)])
+def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, cuda_device):
+    """pcv_conv2d_gated_fused (per-image channel gate between activation and skip add: an SE block inside the convolution)
+    against conv -> x * gate + residual -> ReLU in torch, and pcv_conv1x1_pair_gated_fused bit-identical to the gated launch
+    followed by the second convolution."""
+    import torch.nn as nn
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block
+    N, H, W = shape
+    first = conv1x1_block(in_channels=cm, out_channels=c1, activation=None).eval()
+    second = conv1x1_block(in_channels=c1, out_channels=cm).eval()
+    first.load_state_dict(util.synth_state_dict(first.state_dict(), seed=61))
+    second.load_state_dict(util.synth_state_dict(second.state_dict(), seed=62))
+    first = pytorchcv_amd.set_compute_dtype(first.to(cuda_device), dtype)
+    second = pytorchcv_amd.set_compute_dtype(second.to(cuda_device), dtype)
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(8)
+    x = engine.NHWC(torch.randn((N, H, W, cm), generator=g).to(cuda_device).to(tdt), N, H, W, cm)
+    r = engine.NHWC(torch.randn((N, H, W, c1), generator=g).to(cuda_device).to(tdt), N, H, W, c1)
+    gate = torch.rand((N, c1), generator=g).to(cuda_device).contiguous()
+    with torch.no_grad():
+        plain = first(x)                                            # BN(conv(x)) rounded to 16 bit
+        second(plain)                                               # builds the second runner
+        y1 = first._pcv_runner.run(x, act=0, residual=r, post_act=1, gate=gate)
+        y2 = second(y1)
+        pair = first._pcv_runner.run_pair(x, r, 0, 1, second._pcv_runner, 1, gate=gate)
+    torch.cuda.synchronize()
+    assert pair is not None
+    assert torch.equal(pair[0].t, y1.t) and torch.equal(pair[1].t, y2.t)
+    ref = torch.relu(plain.t.float() * gate[:, None, None, :] + r.t.float())     # differs by the skipped intermediate rounding
+    d = (y1.t.float() - ref).abs()
+    tol = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)
+    assert bool((d <= tol * (plain.t.float().abs() * gate[:, None, None, :] + ref.abs() + 1.0)).all()), float(d.max())
