@@ -184,7 +184,7 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
                            const void* packed2, const float* scale2, const float* shift2, void* y2, void* stream);
 
 /* The pair with pcv_conv2d_gated_fused's per-image channel gate on the first convolution (an SE block run inside it:
- * y1 = post_act(act(BN(conv1(x))) * gate[n, c] + residual)); covered for the LDS-ring kernels (first convolution 128 or 256 in). */
+ * y1 = post_act(act(BN(conv1(x))) * gate[n, c] + residual)); same shapes as pcv_conv1x1_pair_fused. */
 int pcv_conv1x1_pair_gated_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2);
 int pcv_conv1x1_pair_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
                                  const void* packed1, const float* scale1, const float* shift1, const float* gate,

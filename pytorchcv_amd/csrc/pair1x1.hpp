@@ -48,6 +48,9 @@ struct PairParams {
     const float* scale_id;
     const float* shift_id;
     uint32_t x0_bytes, wid_bytes;
+    // GATE: per-image channel gate on the first convolution (an SE block run inside it), fp32 [N][256]; n = pixel / HW
+    const float* gate;
+    FastDiv div_hw;
 };
 
 template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
@@ -56,7 +59,7 @@ template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
 
 // PB: 16-pixel blocks per tile. PB = 4: 64-pixel tiles, one block per CU (needs > 256 registers); PB = 2: 32-pixel tiles,
 // half the accumulators, fits 256 registers and 44 KB of LDS -> two blocks (8 waves) per CU, which hides HBM latency better.
-template <int DT, int PB, bool IDC = false>
+template <int DT, int PB, bool IDC = false, bool GATE = false>
 __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const PairParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int K1 = 64, C1 = 256, C2 = 64, P = 16 * PB;
@@ -287,6 +290,15 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
                     }
                 }
                 apply_act8(v, act1);
+                if constexpr (GATE) {
+#pragma clang fp contract(off)      // as in igemm_conv.hpp: the product is rounded before the skip add
+                    const long pix = (long)tile * P + 16 * j + fr;
+                    const uint32_t n = fastdiv((uint32_t)(pix < p.M ? pix : p.M - 1), p.div_hw);
+                    const float* gp = p.gate + (size_t)n * C1 + 64 * wave + 32 * ip + 8 * fq;
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) unpack2<DT>(resc[ip][j][e], r8[2 * e], r8[2 * e + 1]);
 #pragma unroll

@@ -460,6 +460,9 @@ static int enable_pair(pcv_ctx* ctx) {
         HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fns[i], 256, lds));
         g_pair_blocks_per_cu[i / 2] = nb < 1 ? 1 : nb;
     }
+    const void* gated[2] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 2, false, true>),
+                            reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 2, false, true>)};
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipFuncSetAttribute(gated[i], hipFuncAttributeMaxDynamicSharedMemorySize, pair_lds(2)));
     const void* idc[2] = {reinterpret_cast<const void*>(pair1x1_kernel<PCV_BF16, 2, true>),
                           reinterpret_cast<const void*>(pair1x1_kernel<PCV_F16, 2, true>)};
     for (int i = 0; i < 2; ++i) {
@@ -1325,7 +1328,7 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
 }
 
 int pcv_conv1x1_pair_gated_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2) {
-    return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr && d1->Cin >= 128) ? 1 : 0;      // the LDS-ring kernels only
+    return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr) ? 1 : 0;
 }
 
 int pcv_conv1x1_pair_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
@@ -1376,7 +1379,6 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
         HIP_TRY(ctx, hipLaunchKernel(L.fn, dim3(grid), dim3((unsigned)L.threads), args, (size_t)L.lds, st));
         return PCV_OK;
     }
-    if (gate) return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_gated_fused: the register-resident 64 -> 256 pair has no gate");
     if (P1.wrows != 256 || P1.Kpad != 64 || P2.wrows != 64 || P2.Kpad != 256 || P1.ngb != 1 || P2.ngb != 1)
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
     PairParams p;
@@ -1391,7 +1393,14 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
     p.M = (int)M; p.nTiles = (int)((M + 16 * pb - 1) / (16 * pb));
     p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
     const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_blocks_per_cu[pb == 4 ? 0 : 1]);
-    if (pb == 4) {
+    p.gate = gate;
+    p.div_hw = make_fastdiv((uint32_t)(d1->H * d1->W));
+    if (gate) {
+        const unsigned ggrid = (unsigned)std::min<long>((M + 31) / 32, (long)ctx->num_cu * g_pair_blocks_per_cu[1]);
+        p.nTiles = (int)((M + 31) / 32);
+        if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2, false, true><<<ggrid, 256, pair_lds(2), st>>>(p);
+        else pair1x1_kernel<PCV_F16, 2, false, true><<<ggrid, 256, pair_lds(2), st>>>(p);
+    } else if (pb == 4) {
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 4><<<grid, 256, pair_lds(4), st>>>(p);
         else pair1x1_kernel<PCV_F16, 4><<<grid, 256, pair_lds(4), st>>>(p);
     } else {

@@ -396,7 +396,7 @@ def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("cm,c1", [(128, 512), (256, 1024), (128, 256)])
+@pytest.mark.parametrize("cm,c1", [(64, 256), (128, 512), (256, 1024), (128, 256)])
 @pytest.mark.parametrize("shape", [(3, 13, 11), (5, 28, 28), (9, 14, 14)])
 def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, cuda_device):
     """pcv_conv2d_gated_fused (per-image channel gate between activation and skip add: an SE block inside the convolution)
@@ -426,7 +426,12 @@ def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, cuda_device):
         pair = first._pcv_runner.run_pair(x, r, 0, 1, second._pcv_runner, 1, gate=gate)
     torch.cuda.synchronize()
     assert pair is not None
-    assert torch.equal(pair[0].t, y1.t) and torch.equal(pair[1].t, y2.t)
+    assert torch.equal(pair[0].t, y1.t)
+    if cm == 64:                                                    # the narrow pair sums its K slices in another order: 1 ulp
+        d2 = float((pair[1].t.float() - y2.t.float()).abs().max())
+        assert d2 <= (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10) * max(1.0, float(y2.t.float().abs().max()))
+    else:
+        assert torch.equal(pair[1].t, y2.t)
     ref = torch.relu(plain.t.float() * gate[:, None, None, :] + r.t.float())     # differs by the skipped intermediate rounding
     d = (y1.t.float() - ref).abs()
     tol = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)
