@@ -423,7 +423,7 @@ static int g_pair_blocks_per_cu[2] = {1, 1};                                    
 static int g_wpair_mask = 3;                                                        // bit 0: CM = 128, bit 1: CM = 256 (tuning)
 static int g_wpair_blocks_per_cu[4] = {1, 1, 1, 1};
 // wide pair configurations: 0: 128 -> 512, 1: 256 -> 1024 (ResNet), 2: 128 -> 256, 3: 256 -> 512 (ResNeXt 32x4d)
-struct WPairLaunch { const void* fn; int threads, lds, tileP; };
+struct WPairLaunch { const void* fn; int threads, lds, tileP; bool gate_in_lds; };
 template <int CM, int C1> static WPairLaunch wpair_launch_for(int dt, bool gated) {
     typedef WPairCfg<CM, C1> G;
     const void* fn;
@@ -431,7 +431,7 @@ template <int CM, int C1> static WPairLaunch wpair_launch_for(int dt, bool gated
                                    : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1, true>);
     else fn = dt == PCV_BF16 ? reinterpret_cast<const void*>(wpair1x1_kernel<PCV_BF16, CM, C1, false>)
                              : reinterpret_cast<const void*>(wpair1x1_kernel<PCV_F16, CM, C1, false>);
-    return WPairLaunch{fn, 64 * G::NW, G::LDS, G::P};
+    return WPairLaunch{fn, 64 * G::NW, gated ? G::LDS_GATED : G::LDS, G::P, gated && G::GATE_LDS};
 }
 static WPairLaunch wpair_launch(int cfg, int dt, bool gated = false) {
     switch (cfg) {
@@ -475,7 +475,8 @@ static int enable_pair(pcv_ctx* ctx) {
         for (int dt = PCV_BF16; dt <= PCV_F16; ++dt) {
             const WPairLaunch L = wpair_launch(cfg, dt);
             HIP_TRY(ctx, hipFuncSetAttribute(L.fn, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
-            HIP_TRY(ctx, hipFuncSetAttribute(wpair_launch(cfg, dt, true).fn, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds));
+            HIP_TRY(ctx, hipFuncSetAttribute(wpair_launch(cfg, dt, true).fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             wpair_launch(cfg, dt, true).lds));
             int nb = 0;
             HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, L.fn, L.threads, L.lds));
             g_wpair_blocks_per_cu[cfg] = nb < 1 ? 1 : nb;
@@ -1328,7 +1329,11 @@ int pcv_conv1x1_pair_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv
 }
 
 int pcv_conv1x1_pair_gated_supported(const pcv_conv_desc* d1, const pcv_conv_desc* d2) {
-    return (d1 && d2 && pair_unsupported(*d1, *d2) == nullptr) ? 1 : 0;
+    if (!d1 || !d2 || pair_unsupported(*d1, *d2) != nullptr) return 0;
+    // kernels that stage the gate rows in LDS hold two images' rows per tile: the map must be at least one tile large
+    const int cfg = wpair_cfg(d1->Cin, d1->Cout);
+    if (cfg >= 0 && wpair_launch(cfg, d1->dtype, true).gate_in_lds && d1->H * d1->W < wpair_launch(cfg, d1->dtype, true).tileP) return 0;
+    return 1;
 }
 
 int pcv_conv1x1_pair_gated_fused(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc* d2, const void* x,
@@ -1372,6 +1377,7 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
         const WPairLaunch L = wpair_launch(cfg, d1->dtype, gate != nullptr);
         q.gate = gate;
         q.div_hw = make_fastdiv((uint32_t)(d1->H * d1->W));
+        q.hw = (uint32_t)(d1->H * d1->W);
         q.M = (int)M; q.nTiles = (int)((M + L.tileP - 1) / L.tileP);
         q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
         const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[cfg]);

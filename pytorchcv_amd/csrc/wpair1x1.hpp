@@ -48,6 +48,7 @@ struct WPairParams {
     // pcv_conv2d_gated_fused's epilogue); n = pixel / HW
     const float* gate;
     FastDiv div_hw;
+    uint32_t hw;
 };
 
 template <int N> __device__ __forceinline__ void wpair_wait_vmcnt() {
@@ -71,6 +72,9 @@ template <int CM, int C1_ = 4 * CM> struct WPairCfg {
     static constexpr int XCH = PAIRW ? NWP * 2 * PBW * 1024 : 0;      // exchange buffer [wp][ip][j][lane] x 16 bytes
     static constexpr int TAB = 2 * SLOT + XCH;                        // BN tables: sc1, sf1 [C1], sc2, sf2 [CM]
     static constexpr int LDS = TAB + (2 * C1 + 2 * CM) * 4;
+    // GATE: the gate rows of the (at most two) images a tile touches, double buffered by tile parity - when there is room
+    static constexpr bool GATE_LDS = LDS + 4 * C1 * 4 <= 80 * 1024;
+    static constexpr int LDS_GATED = LDS + (GATE_LDS ? 4 * C1 * 4 : 0);
 };
 
 template <int DT, int CM, int C1_ = 4 * CM, bool GATE = false>
@@ -94,6 +98,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
     float* const tsf1 = tsc1 + C1;
     float* const tsc2 = tsf1 + C1;
     float* const tsf2 = tsc2 + CM;
+    float* const tgate = tsf2 + CM;                     // GATE && G::GATE_LDS: [tile parity][image 0 / 1 of the tile][C1]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -185,6 +190,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
     load_x(tile, xf);
     load_res(tile, 0, resr[0]);
     bool first = true;
+    bool tile_parity = false;
 
     while (true) {
         f32x4 acc2[NI2W][PBW];
@@ -193,14 +199,31 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
 #pragma unroll
             for (int j = 0; j < PBW; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        int gate_n0 = 0;
+        float* gbuf = tgate;
+        if constexpr (GATE && G::GATE_LDS) {
+            // the tile's gate rows -> LDS (visible after chunk 0's barrier; the other parity buffer may still be read by waves
+            // that are finishing the previous tile). Host guarantees HW >= P: a tile touches at most two images.
+            const long first = (long)tile * P;
+            gate_n0 = (int)fastdiv((uint32_t)(first < p.M ? first : p.M - 1), p.div_hw);
+            const int nimg = p.M / (int)p.hw;
+            gbuf = tgate + (tile_parity ? 2 * C1 : 0);
+            for (int i = tid * 4; i < 2 * C1; i += NT * 4) {
+                const int img = i / C1, ch = i - img * C1;
+                const int n = gate_n0 + img < nimg ? gate_n0 + img : nimg - 1;
+                *reinterpret_cast<f32x4*>(gbuf + i) = *reinterpret_cast<const f32x4*>(p.gate + (size_t)n * C1 + ch);
+            }
+        }
         auto chunk = [&](int c, auto PAR) {
             constexpr int par = decltype(PAR)::value;            // c & 1: ring slot and residual register set
             const int cn = c + 1 < NCH ? c + 1 : 0;              // the weights do not depend on the tile: the last chunk
             const int tn = c + 1 < NCH ? tile : tile + tstride;  // requests chunk 0 again, for the next tile
             // DMA(c) of this wave landed: younger VMEM ops are the residual prefetch of chunk c and the y1 stores of
             // chunk c-1; at a tile start also the y2 stores and the x loads: wait for everything there.
-            if (c == 0) wpair_wait_vmcnt<0>();
-            else wpair_wait_vmcnt<YOUNG>();
+            if (c == 0) {
+                wpair_wait_vmcnt<0>();
+                if constexpr (GATE && G::GATE_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the gate rows are written
+            } else wpair_wait_vmcnt<YOUNG>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // next chunk's weights into the slot every wave has finished reading (chunk c-1)
@@ -249,7 +272,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
 #pragma clang fp contract(off)      // as in igemm_conv.hpp: the product is rounded before the skip add
                         const long pix = pix_of(tile, j);
                         const uint32_t n = fastdiv((uint32_t)(pix < p.M ? pix : p.M - 1), p.div_hw);
-                        const float* gp = p.gate + (size_t)n * C1 + ch;
+                        const float* gp = G::GATE_LDS ? gbuf + ((int)n - gate_n0) * C1 + ch : p.gate + (size_t)n * C1 + ch;
                         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
@@ -338,6 +361,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
             }
         }
         tile += tstride;
+        tile_parity = !tile_parity;
         if (tile >= p.nTiles) break;
         load_x(tile, xf);
     }
