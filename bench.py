@@ -34,6 +34,7 @@ WORKLOADS = {
     "efficientnet_b0_bs256": ("efficientnet_b0", 256, "depthwise", "hbm"),
     "vgg16_bs128": ("vgg16", 128, "dense3x3", "mfma"),
     "seresnet50_bs256": ("seresnet50", 256, "dense3x3", "mfma"),
+    "seresnext50_32x4d_bs256": ("seresnext50_32x4d", 256, "grouped3x3", "hbm"),
 }
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"
