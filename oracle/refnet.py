@@ -413,7 +413,7 @@ def bn_act(sd, prefix, x, q=None, act="relu", eps=1e-5):
     return q.r(_act(y, act))
 
 
-def pre_conv_chain(sd, prefixes, strides, a, q=None, residual=None, eps=1e-5):
+def pre_conv_chain(sd, prefixes, strides, a, q=None, residual=None, eps=1e-5, se_prefix=None):
     """A run of PreConvBlocks (conv.py:776-786) whose first pre-activation has already been applied to `a`: block i's
     Conv2d, then block i+1's BatchNorm + ReLU. The GPU path fuses exactly that pair into one launch, so in the
     quantisation-matched mode the value is rounded once per pair; the skip add joins the last convolution."""
@@ -432,6 +432,13 @@ def pre_conv_chain(sd, prefixes, strides, a, q=None, residual=None, eps=1e-5):
                                  False, 0.0, eps)
             a = q.r(F.relu(y))
         else:
+            if se_prefix is not None:
+                # 16-bit pipeline (SEBlock.run_behind): the last convolution is linear in its pre-activated input, so the squeeze
+                # is conv(mean_hw(a)) with fp32 weights, and its unrounded result is scaled, joined with the skip, then rounded
+                sq = F.conv2d(a.mean(dim=(2, 3), keepdim=True), w, b.float() if b is not None else None)
+                g = F.conv2d(sq, sd[se_prefix + "conv1.weight"], sd[se_prefix + "conv1.bias"])
+                g = torch.sigmoid(F.conv2d(F.relu(g), sd[se_prefix + "conv2.weight"], sd[se_prefix + "conv2.bias"]))
+                y = y * g
             if residual is not None:
                 y = y + residual
             a = q.r(y)
@@ -454,6 +461,8 @@ def preres_unit(sd, p, x, stride, bottleneck, conv1_stride, q=None):
         b = sd.get(p + "identity_conv.bias", None)
         identity = q.r(F.conv2d(pre, q.r(sd[p + "identity_conv.weight"].float()), b.float() if b is not None else None, stride))
     if (p + "se.conv1.weight") in sd:
+        if q.on and bottleneck:      # the GPU pipeline runs the SE block inside the last 1x1 convolution: its rounding points
+            return pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q, residual=identity, se_prefix=p + "se.")
         y = pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q)
         return se_block(sd, p + "se.", y, q=q, residual=identity)
     return pre_conv_chain(sd, [p + "body." + n for n in names], strides, pre, q, residual=identity)

@@ -226,7 +226,7 @@ class PreConvBlock(nn.Module):
             self._pcv_pre = engine.BnActRunner(self.bn)
         return self._pcv_pre.run(a, self.act_code())
 
-    def conv_then(self, a, next_block=None, residual=None, out=None):
+    def conv_then(self, a, next_block=None, residual=None, out=None, se=None):
         """This block's convolution applied to the already pre-activated `a`; `next_block`'s BN + activation (the
         pre-activation of the following PreConvBlock) ride in the epilogue, or `residual` is added (last block of a unit)."""
         key = id(next_block)
@@ -234,7 +234,17 @@ class PreConvBlock(nn.Module):
             bn = next_block.bn if (next_block is not None and next_block.normalize) else None
             self._pcv_runners[key] = engine.ConvRunner(self.conv, bn)
         act = next_block.act_code() if next_block is not None else 0
-        return self._pcv_runners[key].run(a, act=act, residual=residual, out=out)
+        runner = self._pcv_runners[key]
+        gate = None
+        c = self.conv
+        if se is not None and next_block is None and out is None and engine.FUSE_UNITS and tuple(c.kernel_size) == (1, 1) and \
+                tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0) and a.dense:
+            # SEBlock `se` follows this (linear) convolution: its gate is computed from the squeezed INPUT and applied in the epilogue
+            w1, b1, w2, b2 = se._mlp()
+            gate = runner.squeezed_excite(a, w1, b1, w2, b2, engine.act_code(se.activ), engine.act_code(se.sigmoid))
+        elif se is not None:
+            return se(runner.run(a, act=act, out=out), residual=residual)
+        return runner.run(a, act=act, residual=residual, out=out, gate=gate)
 
     def _run(self, a):
         pre = self.preact(a) if (self.normalize or self.activate) else a

@@ -53,11 +53,13 @@ class PreResBottleneck(nn.Module):
         return _run_body(self, x)
 
 
-def _chain_forward(blocks, a, residual=None):
-    """`a` is already pre-activated for blocks[0]; block i's convolution carries block i+1's BN+activation."""
+def _chain_forward(blocks, a, residual=None, se=None):
+    """`a` is already pre-activated for blocks[0]; block i's convolution carries block i+1's BN+activation. `se`: the SEBlock
+    that follows the body (SE-PreResNet): it runs inside the last convolution when that is a 1x1 (PreConvBlock.conv_then)."""
     for i, blk in enumerate(blocks):
         last = (i + 1 == len(blocks))
-        a = blk.conv_then(a, next_block=(None if last else blocks[i + 1]), residual=(residual if last else None))
+        a = blk.conv_then(a, next_block=(None if last else blocks[i + 1]), residual=(residual if last else None),
+                          se=(se if last else None))
     return a
 
 

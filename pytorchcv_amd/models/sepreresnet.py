@@ -1,6 +1,7 @@
 """
     SE-PreResNet for ImageNet-1K on the MI355X hot path (reference pytorchcv/models/sepreresnet.py:17-560): PreResNet bodies
-    with an SEBlock between the body and the skip add; the channel scale and the add are one pass (pcv_se_scale).
+    with an SEBlock between the body and the skip add: in the bottleneck nets it runs inside the body's last 1x1 convolution
+    (SEBlock.run_behind / PreConvBlock.conv_then(se=...)), in the basic-block nets the channel scale and the add are one pass (pcv_se_scale).
 """
 
 __all__ = ['SEPreResNet', 'sepreresnet10', 'sepreresnet12', 'sepreresnet14', 'sepreresnet16', 'sepreresnet18',
@@ -35,7 +36,7 @@ class SEPreResUnit(nn.Module):
         blocks = self.body.chain()
         pre = blocks[0].preact(a)
         identity = self.identity_conv(pre) if self.resize_identity else a
-        return self.se(_chain_forward(blocks, pre), residual=identity)
+        return _chain_forward(blocks, pre, residual=identity, se=self.se)
 
     def forward(self, x):
         return engine.boundary(self, x, self._run)
