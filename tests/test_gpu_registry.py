@@ -99,3 +99,27 @@ def test_se_inside_convolution_16bit_vs_oracle(name, cuda_device):
     # 50 uncalibrated bf16 layers drift by a few per cent of max|logit| (activations grow to 1e2..1e3); an SE path applied at the
     # wrong place or with the wrong squeeze is O(1) off
     assert err <= 1e-1 * max(1.0, float(ref.abs().max())), (name, err, float(ref.abs().max()))
+
+
+def test_every_registry_model_runs_and_is_batch_position_invariant(cuda_device):
+    """All registry names once in bf16 (random init, native input size): finite logits of the right shape, and an image's
+    logits do not depend on its position in the batch, bit for bit (net(x)[1] == net(x[1:2])) - the property the batch lanes
+    and the sharded multi-GPU path rely on."""
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model, _models
+    bad = []
+    for name in sorted(_models):
+        torch.manual_seed(0)
+        net = get_model(name).eval()
+        size = net.in_size[0]
+        net = pytorchcv_amd.set_compute_dtype(net.to(cuda_device), "bf16")
+        x = torch.randn(3, 3, size, size, device=cuda_device)
+        with torch.no_grad():
+            y = net(x)
+            y1 = net(x[1:2])
+        torch.cuda.synchronize()
+        if tuple(y.shape) != (3, net.num_classes) or not bool(torch.isfinite(y).all()) or not torch.equal(y[1:2], y1):
+            bad.append(name)
+        del net, y, y1
+        torch.cuda.empty_cache()
+    assert len(_models) >= 139 and not bad, bad
