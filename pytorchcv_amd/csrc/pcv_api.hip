@@ -1023,6 +1023,14 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         if (tile == TILE_C64 && d->Cin >= 256) tile = TILE_C64S;
         else if (tile == TILE_C128 && P.cout_blk <= 128 && d->Cin >= 512) tile = TILE_C128S;
         else if (tile == TILE_C256 && d->Cin > 128) tile = TILE_C128;
+        // Swish / sigmoid epilogues are VALU-bound (two quarter-rate transcendentals per element: the 16 -> 96 expand layer of
+        // EfficientNet at 112x112 takes 384 us with Swish against 215 us with ReLU6): with one or two K-steps per tile the
+        // half-height tiles (3 blocks per CU) overlap that epilogue with other blocks' loads - 13-26 % faster in a tile sweep.
+        // Of the two, the one that pads fewer channel rows; ties go to the 128-row tile (x is re-read less).
+        if ((d->act == PCV_ACT_SWISH || d->act == PCV_ACT_SIGMOID) && P.nk <= 2 && P.ngb == 1 && !d->has_residual) {
+            const int pad64 = round_up(P.cout_blk, 64), pad128 = round_up(P.cout_blk, 128);
+            tile = pad64 < pad128 ? TILE_C64S : TILE_C128S;
+        }
     }
     if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !special && (ctx->force_tile < TILE_C64S || khw == 1))
         tile = ctx->force_tile;
