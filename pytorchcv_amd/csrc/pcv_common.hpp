@@ -95,13 +95,34 @@ template <int N> __device__ __forceinline__ void clampn(float (&v)[N], const Act
 #pragma unroll
     for (int e = 0; e < N; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);
 }
-template <int N> __device__ __forceinline__ void apply_actn(float (&v)[N], const ActClamp& a) {
-    if (a.slow) {
+// the non-clamp activations: ONE uniform switch around a straight unrolled run per case (a switch per element costs eight
+// scalar compare/branch sequences in every epilogue group)
+template <int N> __device__ __forceinline__ void apply_slow_actn(float (&v)[N], int code) {
+    switch (code) {
+        case PCV_ACT_SIGMOID:
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = apply_act(v[e], a.code);
-    } else {
-        clampn<N>(v, a);
+            for (int e = 0; e < N; ++e) v[e] = __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
+            break;
+        case PCV_ACT_SWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __expf(-v[e]));
+            break;
+        case PCV_ACT_HSIGMOID:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+            break;
+        case PCV_ACT_HSWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+            break;
+        default:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = apply_act(v[e], code);
     }
+}
+template <int N> __device__ __forceinline__ void apply_actn(float (&v)[N], const ActClamp& a) {
+    if (a.slow) apply_slow_actn<N>(v, a.code);
+    else clampn<N>(v, a);
 }
 __device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) {
 #pragma unroll
@@ -109,8 +130,7 @@ __device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) {
 }
 __device__ __forceinline__ void apply_act8(float (&v)[8], const ActClamp& a) {
     if (a.slow) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.code);
+        apply_slow_actn<8>(v, a.code);
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);     // clamp in one VALU op
