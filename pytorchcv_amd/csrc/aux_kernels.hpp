@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
                                                       const void* __restrict__ res, void* __restrict__ y, long total8,
                                                       int HW, int C, int post_act) {
     const int C8 = C / 8;
+    const ActClamp pact = make_act(post_act);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         const long pix = i / C8;
@@ -326,10 +327,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
-        if (post_act != PCV_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], post_act);
-        }
+        if (post_act != PCV_ACT_NONE) apply_act8(v, pact);
         store8<DT>(y, (size_t)i * 8, v);
     }
 }
