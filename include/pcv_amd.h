@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define PCV_ABI_VERSION 1
+/* 2: pcv_conv_desc starts with struct_size and ends with y_cpitch (version 1 had neither check; a binding built against
+ * another layout is refused with PCV_ERR_INVALID instead of being read past its end) */
+#define PCV_ABI_VERSION 2
 
 typedef struct pcv_ctx pcv_ctx;
 
@@ -55,6 +57,8 @@ typedef enum pcv_act {
  * mobilenetv2.py:69-70).
  */
 typedef struct pcv_conv_desc {
+    int32_t struct_size;           /* sizeof(pcv_conv_desc) as the CALLER's binding sees it (= pcv_conv_desc_size() of the library it
+                                      was written against); every entry point refuses a descriptor whose size differs */
     int32_t N, H, W;               /* input batch and logical spatial size */
     int32_t Cin, Cout;             /* logical channels (all groups) */
     int32_t kh, kw;
@@ -76,11 +80,13 @@ typedef struct pcv_conv_desc {
 
 /* ---- context ------------------------------------------------------------------------------------------ */
 int pcv_abi_version(void);
+size_t pcv_conv_desc_size(void);                    /* sizeof(pcv_conv_desc) in this build: a binding asserts it once at load time */
 int pcv_create(pcv_ctx** out, int device);
 int pcv_destroy(pcv_ctx* ctx);
 const char* pcv_last_error(const pcv_ctx* ctx);     /* ctx may be NULL: returns the last creation error */
-/* Tuning/debug switches ("persist", "conv3", "conv3_cfg", ...; also settable as PCV_AMD_* environment variables before
- * pcv_create). They select among kernels that compute the same result; nothing in the reference corresponds to them. */
+/* Tuning/debug switches ("persist", "tile", "d3x3", "max_blocks", ...; some also settable as PCV_AMD_* environment variables
+ * before pcv_create). They select among kernels / grid sizes that compute the same result; nothing in the reference
+ * corresponds to them. "max_blocks" (test only) caps every persistent grid so that small inputs walk several tiles per block. */
 int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value);
 
 /* ---- layout: the only NCHW-facing calls ---------------------------------------------------------------- */

@@ -24,16 +24,26 @@ class PcvError(RuntimeError):
         self.code = code
 
 
+PCV_ABI_VERSION = 2
+
+
 class ConvDesc(ctypes.Structure):
-    """Mirror of `pcv_conv_desc` (include/pcv_amd.h)."""
+    """Mirror of `pcv_conv_desc` (include/pcv_amd.h); `struct_size` is filled in by the constructor and checked by the
+    library, and `lib()` compares sizeof(ConvDesc) with `pcv_conv_desc_size()` once at load time."""
     _fields_ = [(n, ctypes.c_int32) for n in (
-        "N", "H", "W", "Cin", "Cout", "kh", "kw", "stride_h", "stride_w", "pad_t", "pad_l", "pad_b", "pad_r",
+        "struct_size", "N", "H", "W", "Cin", "Cout", "kh", "kw", "stride_h", "stride_w", "pad_t", "pad_l", "pad_b", "pad_r",
         "dil_h", "dil_w", "groups", "act", "post_act", "has_residual", "dtype", "out_dtype", "x_cpitch", "x_wpitch",
         "y_cpitch")]
 
 
+    def __init__(self, *args, **kw):
+        super(ConvDesc, self).__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(ConvDesc)
+
+
 _SIGS = {
     "pcv_abi_version": (_I, []),
+    "pcv_conv_desc_size": (ctypes.c_size_t, []),
     "pcv_create": (_I, [ctypes.POINTER(_VP), _I]),
     "pcv_destroy": (_I, [_VP]),
     "pcv_last_error": (ctypes.c_char_p, [_VP]),
@@ -96,6 +106,11 @@ def lib():
                     fn = getattr(L, name)          # AttributeError here = header/library mismatch
                     fn.restype = res
                     fn.argtypes = args
+                if L.pcv_abi_version() != PCV_ABI_VERSION or L.pcv_conv_desc_size() != ctypes.sizeof(ConvDesc):
+                    raise RuntimeError("pytorchcv_amd: {} has ABI version {} / a {}-byte pcv_conv_desc, this binding expects "
+                                       "version {} / {} bytes - rebuild the library".format(
+                                           LIB_PATH, L.pcv_abi_version(), L.pcv_conv_desc_size(), PCV_ABI_VERSION,
+                                           ctypes.sizeof(ConvDesc)))
                 _lib = L
     return _lib
 

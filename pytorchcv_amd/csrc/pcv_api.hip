@@ -9,12 +9,9 @@
 #include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
-#include "conv3x3_inst.hpp"
-#include "hconv3x3_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
-#include "c64conv3x3.hpp"
 #include "gconv3x3.hpp"
 #include "mbconv.hpp"
 #include "dwconv.hpp"
@@ -24,25 +21,17 @@
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
 IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
-CONV3_INSTANCES(CONV3_DECLARE, PCV_BF16)
-CONV3_INSTANCES(CONV3_DECLARE, PCV_F16)
-CONV3_INSTANCES(CONV3_DECLARE, PCV_F32)
-HCONV_INSTANCES(HCONV_DECLARE)
 
 struct pcv_ctx {
     int device = 0;
     std::string err;
     int num_cu = 256;
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
-    int use_conv3 = 0;          // dedicated 8-wave 3x3 kernel: measured 0-12 % SLOWER than the generic 4-wave tiles in an in-process A/B
-                                // (tests/tools/bench_conv.py), so it is off; PCV_AMD_CONV3=1 / pcv_set_tuning("conv3") enables it
-    int force_conv3_cfg = -1;   // PCV_AMD_CONV3_CFG: tuning only
-    int conv3_flags = 0;        // PCV_AMD_C3FLAGS: tuning only
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
-    int use_c64 = 0;            // register-resident-weights 3x3 kernel for 64 -> 64 channels (c64conv3x3.hpp): no faster than the
-                                // generic tile (one wave per SIMD is issue-bound), so it is off; pcv_set_tuning("c64", 1) enables it
-    int use_hconv = 0;          // halo-reuse 3x3 kernel (hconv3x3.hpp) for the eligible 3x3/s1/p1 layers
+    int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where it is instantiated (16-bit, s1/p1, Cin % 64 == 0), 0 = never
+    int max_blocks = 0;         // test-only: cap on every persistent grid (0 = resident blocks), so that small fixtures walk several
+                                // tiles per block through the cross-tile pipelines (pcv_set_tuning("max_blocks", n))
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
 };
@@ -73,6 +62,11 @@ struct DeviceGuard {
 };
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// resident block slots of a persistent launch (CUs x blocks per CU), or the test cap of pcv_set_tuning("max_blocks")
+static inline long long block_slots(const pcv_ctx* ctx, int per_cu) {
+    const long long n = (long long)ctx->num_cu * per_cu;
+    return (ctx->max_blocks > 0 && ctx->max_blocks < n) ? ctx->max_blocks : n;
+}
 static inline int esize(int dt) { return dt == PCV_F32 ? 4 : 2; }
 static inline bool dtype_ok(int dt) { return dt == PCV_F32 || dt == PCV_BF16 || dt == PCV_F16; }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -100,7 +94,12 @@ struct ConvPlan {
     std::vector<uint32_t> ksrc;
 };
 
+// A descriptor built by a binding that mirrors another layout of pcv_conv_desc (a stale ctypes stub) is refused, not read.
+static const char* kStaleDesc = "pcv_conv_desc.struct_size does not match this library (stale binding: compare pcv_conv_desc_size() / PCV_ABI_VERSION)";
+static inline bool desc_stale(const pcv_conv_desc& d) { return d.struct_size != (int32_t)sizeof(pcv_conv_desc); }
+
 static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
+    if (desc_stale(d)) return kStaleDesc;
     if (!dtype_ok(d.dtype) || !dtype_ok(d.out_dtype)) return "unknown dtype";
     if (d.out_dtype != d.dtype && d.out_dtype != PCV_F32) return "out_dtype must equal dtype or be fp32";
     if (d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.groups <= 0) return "non-positive conv dimension";
@@ -316,60 +315,6 @@ static int enable_big_lds(pcv_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// ---- dedicated 3x3 kernel table ----------------------------------------------------------------------------------
-enum Conv3Cfg { C3_128x256 = 0, C3_64x512 = 1, C3_COUNT = 2 };
-struct Conv3Info { int BM, BP, threads, lds; };
-static const Conv3Info kConv3[C3_COUNT] = {
-    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 8) * 128 + 128},
-    {64, 512, 512, 3 * 64 * 128 + 2 * (512 + 8) * 128 + 128},
-};
-typedef void (*conv3_fn)(const Conv3Params);
-template <int DT> static conv3_fn conv3_for(int cfg) {
-    return cfg == C3_128x256 ? conv3x3_kernel<DT, 2, 4> : conv3x3_kernel<DT, 1, 8>;
-}
-static conv3_fn pick_conv3(int dt, int cfg) {
-    if (dt == PCV_BF16) return conv3_for<PCV_BF16>(cfg);
-    if (dt == PCV_F16) return conv3_for<PCV_F16>(cfg);
-    return conv3_for<PCV_F32>(cfg);
-}
-static int g_conv3_blocks_per_cu[3][C3_COUNT];
-static int enable_conv3(pcv_ctx* ctx) {
-    for (int dt = 0; dt < 3; ++dt)
-        for (int cfg = 0; cfg < C3_COUNT; ++cfg) {
-            conv3_fn f = pick_conv3(dt, cfg);
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             kConv3[cfg].lds));
-            int nb = 0;
-            HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(f),
-                                                                      kConv3[cfg].threads, kConv3[cfg].lds));
-            g_conv3_blocks_per_cu[dt][cfg] = nb < 1 ? 1 : nb;
-            if (std::getenv("PCV_AMD_DEBUG"))
-                std::fprintf(stderr, "[pcv] conv3x3 dt=%d cfg=%d: %d blocks/CU\n", dt, cfg, nb);
-        }
-    return PCV_OK;
-}
-
-// ---- halo-reuse 3x3 kernel (hconv3x3.hpp) -----------------------------------------------------------------------------------
-typedef void (*hconv_fn)(const HConvParams);
-struct HConvInfo { int BM, BP, threads, lds; };
-static const HConvInfo kHConv[2] = {
-    {128, 256, 512, 3 * 128 * 128 + 2 * (256 + 128) * 128},
-    {64, 256, 256, 3 * 64 * 128 + 2 * (256 + 128) * 128},
-};
-template <int DT> static hconv_fn hconv_for(int cfg) { return cfg == 0 ? hconv3x3_kernel<DT, 2, 4> : hconv3x3_kernel<DT, 1, 4>; }
-static hconv_fn pick_hconv(int dt, int cfg) {
-    if (dt == PCV_BF16) return hconv_for<PCV_BF16>(cfg);
-    if (dt == PCV_F16) return hconv_for<PCV_F16>(cfg);
-    return hconv_for<PCV_F32>(cfg);
-}
-static int enable_c64(pcv_ctx* ctx) {
-    const void* fns[4] = {reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_BF16, false>),
-                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_BF16, true>),
-                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, false>),
-                          reinterpret_cast<const void*>(c64conv3x3_kernel<PCV_F16, true>)};
-    for (int i = 0; i < 4; ++i) HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kC64Lds));
-    return PCV_OK;
-}
 typedef void (*gconv_fn)(const GConvParams);
 struct GConvLaunch { gconv_fn fn; int lds; };
 static GConvLaunch pick_gconv(int dt, int W) {
@@ -391,14 +336,6 @@ static int enable_gconv(pcv_ctx* ctx) {
         }
     return PCV_OK;
 }
-static int enable_hconv(pcv_ctx* ctx) {
-    for (int dt = 0; dt < 3; ++dt)
-        for (int cfg = 0; cfg < 2; ++cfg)
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_hconv(dt, cfg)),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, kHConv[cfg].lds));
-    return PCV_OK;
-}
-
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
 static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16 + 3 * 2 * 64 * 16;     // weights + 2 patches + the pooled variant's row hand-down
 static int g_stem_blocks_per_cu[2];
@@ -485,6 +422,7 @@ static int enable_pair(pcv_ctx* ctx) {
 }
 // Which (conv, next conv) pairs the fused kernel covers: 1x1/s1 64 -> 256 with residual, then 1x1/s1 256 -> 64, 16 bit.
 static const char* pair_unsupported(const pcv_conv_desc& a, const pcv_conv_desc& b) {
+    if (desc_stale(a) || desc_stale(b)) return kStaleDesc;
     auto plain1x1 = [](const pcv_conv_desc& d) {
         return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
                d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
@@ -534,6 +472,7 @@ static int enable_mbconv(pcv_ctx* ctx) {
 }
 // de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
 static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_desc& dd, const pcv_conv_desc& dp) {
+    if ((de && desc_stale(*de)) || desc_stale(dd) || desc_stale(dp)) return kStaleDesc;
     auto plain1x1 = [](const pcv_conv_desc& d) {
         return d.kh == 1 && d.kw == 1 && d.stride_h == 1 && d.stride_w == 1 && d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 &&
                d.pad_r == 0 && d.groups == 1 && d.dil_h == 1 && d.dil_w == 1 && d.out_dtype == d.dtype &&
@@ -603,6 +542,8 @@ extern "C" {
 
 int pcv_abi_version(void) { return PCV_ABI_VERSION; }
 
+size_t pcv_conv_desc_size(void) { return sizeof(pcv_conv_desc); }
+
 const char* pcv_last_error(const pcv_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int pcv_create(pcv_ctx** out, int device) {
@@ -626,14 +567,7 @@ int pcv_create(pcv_ctx** out, int device) {
     ctx->num_cu = prop.multiProcessorCount;
     if (const char* e = std::getenv("PCV_AMD_PERSIST")) ctx->persist_mode = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
-    if (const char* e = std::getenv("PCV_AMD_CONV3")) ctx->use_conv3 = std::atoi(e);
-    if (const char* e = std::getenv("PCV_AMD_HCONV")) ctx->use_hconv = std::atoi(e);
-    if (const char* e = std::getenv("PCV_AMD_CONV3_CFG")) ctx->force_conv3_cfg = std::atoi(e);
-    if (const char* e = std::getenv("PCV_AMD_C3FLAGS")) ctx->conv3_flags = std::atoi(e);
     int rc = enable_big_lds(ctx);
-    if (rc == PCV_OK) rc = enable_conv3(ctx);
-    if (rc == PCV_OK) rc = enable_hconv(ctx);
-    if (rc == PCV_OK) rc = enable_c64(ctx);
     if (rc == PCV_OK) rc = enable_gconv(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
@@ -656,14 +590,11 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     const std::string k(key);
     if (k == "persist") ctx->persist_mode = value;
     else if (k == "persist_nk") ctx->persist_max_nk = value;
-    else if (k == "conv3") ctx->use_conv3 = value;
-    else if (k == "conv3_cfg") ctx->force_conv3_cfg = value;
-    else if (k == "c3flags") ctx->conv3_flags = value;
     else if (k == "tile") ctx->force_tile = value;
     else if (k == "pair_pb") ctx->pair_pb = value;
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
-    else if (k == "hconv") ctx->use_hconv = value;
-    else if (k == "c64") ctx->use_c64 = value;
+    else if (k == "max_blocks") ctx->max_blocks = value;
+    else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
@@ -775,6 +706,7 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
 }
 
 static const char* check_dw(const pcv_conv_desc& d) {
+    if (desc_stale(d)) return kStaleDesc;
     if (!dtype_ok(d.dtype) || d.out_dtype != d.dtype) return "depthwise: out_dtype must equal dtype";
     if (d.groups != d.Cin || d.Cin != d.Cout) return "depthwise: needs groups == Cin == Cout";
     if (d.Cin % 8 != 0) return "depthwise: channels must be a multiple of 8";
@@ -874,7 +806,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         q.act = d->act;
         if (d->has_residual || d->post_act != PCV_ACT_NONE)
             return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel has no residual / post-activation path");
-        long long nb = (long long)ctx->num_cu * g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1];
+        long long nb = block_slots(ctx, g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1]);
         if (nb > nT) nb = nT;
         nb = (nb + 7) / 8 * 8;
         if (pool) {
@@ -904,104 +836,13 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         q.act = d->act;
         const GConvLaunch L = pick_gconv(d->dtype, d->W);
         const int wi = d->W + 1 <= 16 ? 0 : (d->W + 1 <= 32 ? 1 : 2);
-        long long nb = (long long)ctx->num_cu * g_gconv_blocks_per_cu[wi];
+        long long nb = block_slots(ctx, g_gconv_blocks_per_cu[wi]);
         if (nb > nT) nb = nT;
         nb = (nb + 7) / 8 * 8;
         hipLaunchKernelGGL(L.fn, dim3((unsigned)nb), dim3(256), L.lds, (hipStream_t)stream, q);
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
-    if (P.conv3 && !gate && ctx->use_c64 && !sliced_y && d->Cin == 64 && d->Cout == 64 && d->W <= 63 && d->dtype != PCV_F32 &&
-        (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * 64ull * 2ull < 0x80000000ull && P.Kpad == 576) {
-        HConvParams q;
-        std::memset(&q, 0, sizeof(q));
-        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
-        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
-        q.y_bytes = (uint32_t)(M64 * 64ull * 2ull);
-        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = 64; q.Cout = 64;
-        q.HW = d->H * d->W;
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
-        q.CS = 1; q.Kpad = P.Kpad;
-        q.act = d->act; q.post_act = d->post_act;
-        q.nChTiles = 1;
-        const long long nT = (long long)((M64 + 255) / 256);
-        q.nTiles = (int)nT;
-        long long nb = (long long)ctx->num_cu;                        // one 512-register block per CU
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        const bool bf = d->dtype == PCV_BF16;
-        hipStream_t st = (hipStream_t)stream;
-        if (d->has_residual) {
-            if (bf) c64conv3x3_kernel<PCV_BF16, true><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
-            else c64conv3x3_kernel<PCV_F16, true><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
-        } else {
-            if (bf) c64conv3x3_kernel<PCV_BF16, false><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
-            else c64conv3x3_kernel<PCV_F16, false><<<(unsigned)nb, 256, kC64Lds, st>>>(q);
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-    if (P.conv3 && !gate && ctx->use_hconv && !sliced_y && d->W <= 63 && d->Cout % 8 == 0 && d->out_dtype == d->dtype &&
-        (d->x_cpitch == 0 || d->x_cpitch == d->Cin) && M64 * (unsigned long long)d->Cout * P.ES < 0x80000000ull) {
-        HConvParams q;
-        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
-        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
-        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * P.ES);
-        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.Cout = d->Cout;
-        q.HW = d->H * d->W;
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
-        q.CS = d->Cin / (8 * P.CE);
-        q.Kpad = P.Kpad;
-        q.act = d->act; q.post_act = d->post_act;
-        const int cfg = d->Cout <= 64 ? 1 : 0;
-        const HConvInfo& T = kHConv[cfg];
-        q.nChTiles = (d->Cout + T.BM - 1) / T.BM;
-        const long long nT = ((M64 + T.BP - 1) / T.BP) * q.nChTiles;
-        q.nTiles = (int)nT;
-        long long nb = (long long)ctx->num_cu;                        // one block per CU (120-144 KB of LDS)
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        hipLaunchKernelGGL(pick_hconv(d->dtype, cfg), dim3((unsigned)nb), dim3(T.threads), T.lds, (hipStream_t)stream, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-    bool take_conv3 = P.conv3 && !gate && ctx->use_conv3 && !sliced_y;
-    if (take_conv3 && ctx->force_conv3_cfg < 0) {
-        const int c3 = d->Cout <= 64 ? C3_64x512 : C3_128x256;
-        const long long tiles = ((long long)((M64 + kConv3[c3].BP - 1) / kConv3[c3].BP)) * ((d->Cout + kConv3[c3].BM - 1) / kConv3[c3].BM);
-        take_conv3 = tiles * 10 >= (long long)ctx->num_cu * 9;      // fewer tiles than CUs: the 4-wave generic tiles fill better
-    }
-    if (take_conv3) {
-        Conv3Params q;
-        q.x = x; q.res = d->has_residual ? residual : nullptr; q.y = y; q.scale = scale; q.shift = shift;
-        q.w = static_cast<const char*>(packed) + P.ktab_bytes;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
-        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.Cout = d->Cout;
-        q.HW = d->H * d->W;
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
-        q.CS = d->Cin / (8 * P.CE);
-        q.Kpad = P.Kpad;
-        q.act = d->act; q.post_act = d->post_act;
-        q.flags = ctx->conv3_flags;
-        int cfg = d->Cout <= 64 ? C3_64x512 : C3_128x256;
-        if (ctx->force_conv3_cfg >= 0 && ctx->force_conv3_cfg < C3_COUNT) cfg = ctx->force_conv3_cfg;
-        const Conv3Info& T3 = kConv3[cfg];
-        q.nChTiles = (d->Cout + T3.BM - 1) / T3.BM;
-        const long long nT = ((M64 + T3.BP - 1) / T3.BP) * q.nChTiles;
-        q.nTiles = (int)nT;
-        long long nb = (long long)ctx->num_cu * g_conv3_blocks_per_cu[d->dtype][cfg];
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        hipLaunchKernelGGL(pick_conv3(d->dtype, cfg), dim3((unsigned)nb), dim3(T3.threads), T3.lds, (hipStream_t)stream, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-
     const bool ragged = (d->Cout % 8 != 0) || (P.cout_blk % 8 != 0);
     int tile;
     if (ragged || d->out_dtype != d->dtype) tile = TILE_C128;
@@ -1098,7 +939,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     // Short K loops (HBM-bound 1x1 layers) run persistent, so that the next tile's loads overlap this tile's
     // epilogue; long K loops run one tile per block (the dispatcher refills a CU while the finished block's stores drain).
     const bool persistent = ctx->persist_mode == 1 || (ctx->persist_mode < 0 && P.nk <= ctx->persist_max_nk);
-    long long nblocks = persistent ? (long long)ctx->num_cu * bpc : nTiles;
+    long long nblocks = persistent ? block_slots(ctx, bpc) : nTiles;
     if (nblocks > nTiles) nblocks = nTiles;
     nblocks = (nblocks + 7) / 8 * 8;
     dim3 grid((unsigned)nblocks);
@@ -1314,7 +1155,7 @@ int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* res
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_scale: bad argument (C must be a multiple of 8)");
     const long total8 = (long)N * HW * (C / 8);
     long blocks = (total8 + 255) / 256;
-    const long cap = (long)ctx->num_cu * 16;
+    const long cap = (long)block_slots(ctx, 16);
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
@@ -1390,7 +1231,7 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
         q.hw = (uint32_t)(d1->H * d1->W);
         q.M = (int)M; q.nTiles = (int)((M + L.tileP - 1) / L.tileP);
         q.act1 = d1->act; q.post1 = d1->post_act; q.act2 = d2->act;
-        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)ctx->num_cu * g_wpair_blocks_per_cu[cfg]);
+        const unsigned grid = (unsigned)std::min<long>(q.nTiles, (long)block_slots(ctx, g_wpair_blocks_per_cu[cfg]));
         void* args[] = {&q};
         HIP_TRY(ctx, hipLaunchKernel(L.fn, dim3(grid), dim3((unsigned)L.threads), args, (size_t)L.lds, st));
         return PCV_OK;
@@ -1408,11 +1249,11 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
     const int pb = ctx->pair_pb == 4 ? 4 : 2;
     p.M = (int)M; p.nTiles = (int)((M + 16 * pb - 1) / (16 * pb));
     p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
-    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_blocks_per_cu[pb == 4 ? 0 : 1]);
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)block_slots(ctx, g_pair_blocks_per_cu[pb == 4 ? 0 : 1]));
     p.gate = gate;
     p.div_hw = make_fastdiv((uint32_t)(d1->H * d1->W));
     if (gate) {
-        const unsigned ggrid = (unsigned)std::min<long>((M + 31) / 32, (long)ctx->num_cu * g_pair_blocks_per_cu[1]);
+        const unsigned ggrid = (unsigned)std::min<long>((M + 31) / 32, (long)block_slots(ctx, g_pair_blocks_per_cu[1]));
         p.nTiles = (int)((M + 31) / 32);
         if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2, false, true><<<ggrid, 256, pair_lds(2), st>>>(p);
         else pair1x1_kernel<PCV_F16, 2, false, true><<<ggrid, 256, pair_lds(2), st>>>(p);
@@ -1428,6 +1269,7 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
 }
 
 static const char* pair_idconv_unsupported(const pcv_conv_desc& di, const pcv_conv_desc& a, const pcv_conv_desc& b) {
+    if (desc_stale(di)) return kStaleDesc;
     if (const char* why = pair_unsupported(a, b)) return why;
     if (a.Cin != 64) return "identity-convolution variant: only the 64 -> 256 -> 64 pair is instantiated";
     const bool plain = di.kh == 1 && di.kw == 1 && di.stride_h == 1 && di.stride_w == 1 && di.pad_t == 0 && di.pad_l == 0 &&
@@ -1478,7 +1320,7 @@ int pcv_conv1x1_pair_idconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_id, const
     p.w1_bytes = p.wid_bytes = 256 * 64 * 2; p.w2_bytes = 64 * 256 * 2;
     p.M = (int)M; p.nTiles = (int)((M + 31) / 32);
     p.act1 = d1->act; p.post1 = d1->post_act; p.act2 = d2->act;
-    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * g_pair_idc_blocks_per_cu);
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)block_slots(ctx, g_pair_idc_blocks_per_cu));
     hipStream_t st = (hipStream_t)stream;
     if (d1->dtype == PCV_BF16) pair1x1_kernel<PCV_BF16, 2, true><<<grid, 256, pair_lds(2, true), st>>>(p);
     else pair1x1_kernel<PCV_F16, 2, true><<<grid, 256, pair_lds(2, true), st>>>(p);
@@ -1590,7 +1432,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     int nb = 0;
     HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(fn), 256, lds.total));
     if (nb < 1) nb = 1;
-    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)ctx->num_cu * nb);
+    const unsigned grid = (unsigned)std::min<long>(p.nTiles, (long)block_slots(ctx, nb));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds.total, (hipStream_t)stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
@@ -1606,7 +1448,7 @@ int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shi
         return fail(ctx, PCV_ERR_INVALID, "pcv_bn_act: bad argument (C and x_cpitch must be multiples of 8, x_cpitch >= C)");
     const long total8 = rows * (C / 8);
     long blocks = (total8 + 255) / 256;
-    const long cap = (long)ctx->num_cu * 16;
+    const long cap = (long)block_slots(ctx, 16);
     if (blocks > cap) blocks = cap;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);

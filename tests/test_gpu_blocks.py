@@ -109,42 +109,48 @@ def test_train_mode_is_refused(cuda_device):
         blk(torch.zeros(1, 32, 4, 4, device=cuda_device))
 
 
-# ---- dedicated 3x3 kernel: shapes that exercise every tile configuration, tile tails and image borders -------------
+# ---- persistent grids: every kernel test below also runs with the grid capped at 8 blocks (pcv_set_tuning "max_blocks"), so
+# that each block walks several tiles, incl. a ragged last round, through the cross-tile software pipelines - the code path
+# the full-batch benchmark runs (1568 tiles on 512 slots) at fixture size.
+GRIDS = [0, 8]
+GRID_IDS = ["resident", "cap8"]
+
+
+# ---- dense 3x3: shapes that exercise every tile configuration, tile tails and image borders ---------------------------
 _CONV3_SHAPES = [
     # (N, C, Cout, H, W, residual)
-    (2, 64, 64, 56, 56, False),      # 64ch x 512px tiles, M = 6272 (12.25 tiles)
-    (3, 128, 128, 28, 28, True),     # 128x128 / 128x256, M = 2352
+    (2, 64, 64, 56, 56, False),      # 64-channel tile, M = 6272 (24.5 tiles of 256 pixels)
+    (3, 128, 128, 28, 28, True),     # M = 2352 (18.4 tiles of 128 pixels)
     (2, 256, 256, 14, 14, True),     # two channel tiles
+    (16, 256, 256, 14, 14, True),    # 49 tiles: 6.1 per block on the capped grid
     (5, 512, 512, 7, 7, False),      # images smaller than a tile: many image borders inside one tile
+    (40, 512, 512, 7, 7, True),      # 62 tiles of 128x128
     (1, 64, 192, 10, 14, False),     # H != W, Cout not a multiple of the 128-channel tile
     (40, 128, 64, 9, 5, True),       # tiny odd maps, several tiles, 64-channel config with residual
-    (1, 64, 64, 5, 63, True),        # widest map the halo kernel stages (W + 1 = 64)
-    (1, 64, 128, 3, 70, False),      # wider than that: the halo kernel must hand over to the generic path
+    (1, 64, 64, 5, 63, True),
+    (1, 64, 128, 3, 70, False),
 ]
 
 
-@pytest.mark.parametrize("use_conv3", [False, True, "hconv"], ids=["generic", "conv3x3_kernel", "hconv3x3_kernel"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("kernel", ["generic", "d3x3"])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
-def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
+def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device):
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv3x3_block
     from oracle import refnet
+    if kernel == "d3x3" and dtype == "fp32":
+        pytest.skip("the 8-wave dense 3x3 kernel is 16-bit only; fp32 takes the generic implicit GEMM")
     N, C, Cout, H, W, use_res = shape
     blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
     sd = util.synth_state_dict(blk.state_dict(), seed=77)
     blk.load_state_dict(sd)
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
-    from pytorchcv_amd import _lib
-    ctx = _lib.ctx_for(0)
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 1 if use_conv3 is True else 0), ctx)
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 0), ctx)    # the 64 -> 64 kernel has its own test below
-    hconv_default = 0                                             # restored below (the product default: off)
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"hconv", 1 if use_conv3 == "hconv" else 0), ctx)
     x = util.synth_input(N, C, H, W, seed=21)
     res = util.synth_input(N, Cout, H, W, seed=22) if use_res else None
-    with torch.no_grad():
+    with torch.no_grad(), util.tuning(max_blocks=grid, d3x3=1 if kernel == "d3x3" else 0):
         xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
         rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
         y = engine.to_nchw(blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)).cpu()
@@ -152,8 +158,48 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None,
                             post_act="relu" if use_res else None)
     d = (y - ref).abs()
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"conv3", 0), ctx)
-    _lib.check(_lib.lib().pcv_set_tuning(ctx, b"hconv", hconv_default), ctx)
+    if dtype == "fp32":
+        assert float(d.max()) <= 1e-3
+    else:
+        assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
+_CONV1_SHAPES = [
+    # (N, Cin, Cout, H, W, stride, residual): 1x1 layers with several K-steps per tile (nk > 1) on every tile shape
+    (4, 256, 64, 28, 28, 1, False),      # 64-channel half-height tile, nk = 4
+    (4, 512, 128, 28, 28, 1, False),     # 128-channel half-height tile, nk = 8
+    (8, 256, 512, 28, 28, 2, False),     # stride-2 identity convolution, 128x128 tiles
+    (16, 1024, 256, 14, 14, 1, False),   # nk = 16, 25 x 2 tiles
+    (16, 512, 2048, 7, 7, 1, True),      # residual epilogue, 7 x 16 tiles
+    (2, 64, 256, 56, 56, 1, True),       # weight-stationary (nk = 1), 256-channel tile
+    (3, 320, 1280, 7, 7, 1, False),      # Cin not a multiple of the 64-element K-step (zero-filled chunks)
+]
+
+
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", _CONV1_SHAPES, ids=["x".join(str(v) for v in s[:6]) + ("_res" if s[6] else "") for s in _CONV1_SHAPES])
+def test_conv1x1_multi_kstep_shapes_vs_oracle(shape, dtype, grid, cuda_device):
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block
+    from oracle import refnet
+    N, C, Cout, H, W, stride, use_res = shape
+    blk = conv1x1_block(in_channels=C, out_channels=Cout, stride=stride).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=79)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = util.synth_input(N, C, H, W, seed=23)
+    res = util.synth_input(N, Cout, Ho, Wo, seed=24) if use_res else None
+    with torch.no_grad(), util.tuning(max_blocks=grid):
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        y = engine.to_nchw(blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)).cpu()
+    q = refnet.Quant(None if dtype == "fp32" else dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), stride=stride, q=q, residual=q.r(res) if use_res else None,
+                            post_act="relu" if use_res else None)
+    d = (y - ref).abs()
     if dtype == "fp32":
         assert float(d.max()) <= 1e-3
     else:
@@ -162,8 +208,9 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, use_conv3, cuda_device):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("cm", [64, 128, 256, (128, 256), (256, 512)], ids=["64x4", "128x4", "256x4", "128x2", "256x2"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 8, 8), (5, 28, 28), (9, 14, 14)])
-def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
+def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, grid, cuda_device):
     """pcv_conv1x1_pair_fused (unit's last 1x1 + skip add + ReLU, then the next unit's first 1x1) against the same two
     ConvBlocks run as separate launches; pixel counts that are not a multiple of the 64-pixel tile included."""
     import torch.nn as nn
@@ -184,9 +231,10 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
     r = engine.NHWC(torch.randn((N, H, W, c1), generator=g).to(cuda_device).to(tdt), N, H, W, c1)
     relu = nn.ReLU()
     with torch.no_grad():
-        y1_ref = first(x, residual=r, post_act=relu)
+        y1_ref = first(x, residual=r, post_act=relu)            # reference launches on the resident grid
         y2_ref = second(y1_ref)
-        pair = conv_block_pair(first, x, r, relu, second)
+        with util.tuning(max_blocks=grid):
+            pair = conv_block_pair(first, x, r, relu, second)
     assert pair is not None, "the 64 -> 256 -> 64, 128 -> 512 -> 128 and 256 -> 1024 -> 256 pairs must be covered by the fused kernels"
     torch.cuda.synchronize()
     y1, y2 = pair
@@ -201,8 +249,9 @@ def test_conv1x1_pair_fused_matches_two_launches(shape, cm, dtype, cuda_device):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", [(3, 13, 11), (2, 56, 56), (1, 5, 7)])
-def test_conv1x1_pair_idconv_fused_matches_three_launches(shape, dtype, cuda_device):
+def test_conv1x1_pair_idconv_fused_matches_three_launches(shape, dtype, grid, cuda_device):
     """pcv_conv1x1_pair_idconv_fused: identity 1x1 convolution of the unit input recomputed inside the fused pair, against
     identity conv -> conv3 (+ skip, ReLU) -> next conv1 as three launches. The skip tensor is rounded to the storage type at
     the same point, so y1 is bit-identical."""
@@ -225,7 +274,8 @@ def test_conv1x1_pair_idconv_fused_matches_three_launches(shape, dtype, cuda_dev
     with torch.no_grad():
         y1_ref = first(x, residual=ident(x0), post_act=relu)
         y2_ref = second(y1_ref)
-        pair = conv_block_pair(first, x, None, relu, second, id_block=ident, x0=x0)
+        with util.tuning(max_blocks=grid):
+            pair = conv_block_pair(first, x, None, relu, second, id_block=ident, x0=x0)
     assert pair is not None, "the 64 -> 256 identity-convolution pair must be covered by the fused kernel"
     torch.cuda.synchronize()
     y1, y2 = pair
@@ -255,8 +305,9 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
-def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, cuda_device):
+def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, grid, cuda_device):
     """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
     launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle."""
     import pytorchcv_amd
@@ -277,7 +328,8 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, cuda_de
     a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
     residual = a if unit.residual else None
     with torch.no_grad():
-        fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
+        with util.tuning(max_blocks=grid):
+            fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
         if act is None:
             assert fused is None, "576 expanded channels x 96 inputs do not fit the LDS budget: must fall back"
             return
@@ -302,8 +354,9 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, cuda_de
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", [(2, 224, 224), (3, 32, 32), (2, 33, 35), (1, 70, 50), (2, 61, 224), (1, 30, 30)])
-def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, cuda_device):
+def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, grid, cuda_device):
     """pcv_conv2d_maxpool_fused (7x7/2 stem + BN + ReLU + MaxPool2d(3, 2, 1) in one launch) is bit-identical to the stem
     launch followed by pcv_maxpool2d, including odd sizes where pooling windows hang over the border."""
     import pytorchcv_amd
@@ -316,54 +369,17 @@ def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, cuda_device):
     x = util.synth_input(N, 3, H, W, seed=78).to(cuda_device)
     with torch.no_grad():
         a = engine.from_nchw(x, dtype, stem=True)
-        fused = blk.conv._pcv_runner.run_maxpool(a, 1, 3, 2, 1) if blk.conv._pcv_runner is not None else None
-        if fused is None:
-            blk(x)                                  # builds the runner
+        blk(x)                                      # builds the runner
+        with util.tuning(max_blocks=grid):          # fused AND stand-alone stem kernel on the capped grid; the pooling reference is not persistent
             fused = blk.conv._pcv_runner.run_maxpool(a, 1, 3, 2, 1)
-        assert fused is not None, "the 7x7/2 stem + MaxPool2d(3, 2, 1) must be covered by the fused kernel"
-        two = blk.pool(blk.conv(a))
+            assert fused is not None, "the 7x7/2 stem + MaxPool2d(3, 2, 1) must be covered by the fused kernel"
+            c_cap = blk.conv(a)
+        c_res = blk.conv(a)
+        assert torch.equal(c_cap.t, c_res.t)
+        two = blk.pool(c_res)
     torch.cuda.synchronize()
     assert fused.t.shape == two.t.shape and (fused.H, fused.W) == (two.H, two.W)
     assert torch.equal(fused.t, two.t)
-
-
-_C64_SHAPES = [(2, 56, 56), (1, 5, 63), (40, 9, 5), (3, 7, 7), (1, 1, 1), (9, 28, 28), (2, 63, 63), (7, 14, 30)]
-
-
-@pytest.mark.parametrize("use_res", [False, True], ids=["plain", "res"])
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", _C64_SHAPES, ids=["x".join(str(v) for v in s) for s in _C64_SHAPES])
-def test_c64_conv3x3_kernel_equals_generic_and_oracle(shape, dtype, use_res, cuda_device):
-    """c64conv3x3_kernel (64 -> 64 channels, all weights in registers, halo tile staged once): bit-identical to the generic
-    implicit GEMM (same K order) and within the 16-bit bound of the oracle; multi-tile, tile tails, many image borders per tile,
-    the widest supported map (W = 63) and a single pixel."""
-    import pytorchcv_amd
-    from pytorchcv_amd import engine, _lib
-    from pytorchcv_amd.models.common.conv import conv3x3_block
-    from oracle import refnet
-    N, H, W = shape
-    blk = conv3x3_block(in_channels=64, out_channels=64).eval()
-    sd = util.synth_state_dict(blk.state_dict(), seed=91)
-    blk.load_state_dict(sd)
-    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
-    ctx = _lib.ctx_for(0)
-    x = util.synth_input(N, 64, H, W, seed=92)
-    res = util.synth_input(N, 64, H, W, seed=93) if use_res else None
-    relu = torch.nn.ReLU() if use_res else None
-    with torch.no_grad():
-        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
-        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
-        _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 1), ctx)
-        y_new = blk(xh, residual=rh, post_act=relu).t.clone()
-        _lib.check(_lib.lib().pcv_set_tuning(ctx, b"c64", 0), ctx)
-        y_gen = blk(xh, residual=rh, post_act=relu)
-        y = engine.to_nchw(engine.NHWC(y_new, N, H, W, 64)).cpu()
-    torch.cuda.synchronize()
-    assert torch.equal(y_new, y_gen.t)
-    q = refnet.Quant(dtype)
-    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
-    d = (y - ref).abs()
-    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
 _GCONV_SHAPES = [  # (N, C, groups, H, W): 4 / 8 / 16 channels per group, every halo width class (W <= 15, <= 31, <= 63) and beyond
@@ -373,8 +389,9 @@ _GCONV_SHAPES = [  # (N, C, groups, H, W): 4 / 8 / 16 channels per group, every 
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", _GCONV_SHAPES, ids=["x".join(str(v) for v in s) for s in _GCONV_SHAPES])
-def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
+def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, grid, cuda_device):
     """gconv3x3_kernel (grouped 3x3 with 4 / 8 / 16 channels per group: halo tile staged once, K = tap pair x 16 channels) against
     the oracle; W = 70 is wider than the halo scheme stages and must take the generic path with the same result."""
     import pytorchcv_amd
@@ -387,7 +404,7 @@ def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
     blk.load_state_dict(sd)
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
     x = util.synth_input(N, C, H, W, seed=56)
-    with torch.no_grad():
+    with torch.no_grad(), util.tuning(max_blocks=grid):
         y = engine.to_nchw(blk(engine.from_nchw(x.to(cuda_device), dtype, stem=False))).cpu()
     q = refnet.Quant(dtype)
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, groups=groups, q=q)
@@ -397,8 +414,9 @@ def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, cuda_device):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("cm,c1", [(64, 256), (128, 512), (256, 1024), (128, 256)])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", [(3, 13, 11), (5, 28, 28), (9, 14, 14)])
-def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, cuda_device):
+def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, grid, cuda_device):
     """pcv_conv2d_gated_fused (per-image channel gate between activation and skip add: an SE block inside the convolution)
     against conv -> x * gate + residual -> ReLU in torch, and pcv_conv1x1_pair_gated_fused bit-identical to the gated launch
     followed by the second convolution."""
@@ -423,7 +441,10 @@ def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, cuda_device):
         second(plain)                                               # builds the second runner
         y1 = first._pcv_runner.run(x, act=0, residual=r, post_act=1, gate=gate)
         y2 = second(y1)
-        pair = first._pcv_runner.run_pair(x, r, 0, 1, second._pcv_runner, 1, gate=gate)
+        with util.tuning(max_blocks=grid):
+            y1_cap = first._pcv_runner.run(x, act=0, residual=r, post_act=1, gate=gate)
+            pair = first._pcv_runner.run_pair(x, r, 0, 1, second._pcv_runner, 1, gate=gate)
+        assert torch.equal(y1_cap.t, y1.t)
     torch.cuda.synchronize()
     assert pair is not None
     assert torch.equal(pair[0].t, y1.t)

@@ -60,6 +60,40 @@ def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_devic
     assert raw <= (0.5 if dtype == "bf16" else 0.08)
 
 
+# BASELINE.json configs 2-4 (+ resnet18 at the same batch): the batches bench.py times. At these sizes every persistent kernel
+# walks several rounds of tiles per block (ResNet-50's 3x3 layers: 1568 tiles on 512 slots) and the graph runs two batch lanes.
+_HEADLINE = [("resnet50", 256), ("mobilenetv2_w1", 512), ("resnext101_32x4d", 256), ("resnet18", 256)]
+
+
+@pytest.mark.parametrize("name,batch", _HEADLINE, ids=["{}-{}".format(n, b) for n, b in _HEADLINE])
+def test_headline_batch_matches_fixture(name, batch, cuda_device):
+    """The 4 golden images tiled to the full benchmark batch: every row of the eager forward AND of the 2-lane hipGraph
+    replay is bit-identical to the 4-image forward (whose distance to the oracle / the reference golden the tests above
+    bound), i.e. the multi-round tile schedules and the lane split compute exactly what the fixtures check.
+    Reference behaviour: net(x) at any batch, pytorchcv/models/resnet.py:333-337."""
+    from pytorchcv_amd.graph import capture
+    logits, ids = util.model_golden(name)
+    net = _net(name, "bf16", cuda_device)
+    x4 = util.images(ids).to(cuda_device)
+    with torch.no_grad():
+        y4 = net(x4).clone()
+        x = x4.repeat(batch // 4, 1, 1, 1).contiguous()
+        y_eager = net(x).clone()
+        g = capture(net, x, lanes=2)
+        assert g.lanes == 2
+        y_graph = g(x, clone=True)
+    torch.cuda.synchronize()
+    want = y4.repeat(batch // 4, 1)
+    assert y_eager.shape == (batch, 1000)
+    assert torch.equal(y_eager, want), "eager full batch differs from the 4-image forward in {} rows".format(
+        int((y_eager != want).any(1).sum()))
+    assert torch.equal(y_graph, want), "2-lane graph differs from the 4-image forward in {} rows".format(
+        int((y_graph != want).any(1).sum()))
+    assert torch.equal(y_graph.argmax(1).cpu(), logits.argmax(1).repeat(batch // 4))      # top-1 of the reference forward
+    del g, x, y_eager, y_graph
+    torch.cuda.empty_cache()
+
+
 def test_batch_independence_and_determinism(cuda_device):
     """Image i's logits do not depend on the rest of the batch, and a rerun is bit-identical."""
     net = _net("resnet18", "bf16", cuda_device)

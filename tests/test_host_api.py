@@ -28,19 +28,88 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libpcv_amd.so does not export {}".format(name)
     assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table and header disagree"
-    assert L.pcv_abi_version() == 1
+    assert L.pcv_abi_version() == _lib.PCV_ABI_VERSION == _header_abi_version()
 
 
-def test_conv_desc_matches_header_layout():
-    from pytorchcv_amd._lib import ConvDesc
+def _header_abi_version():
+    text = open(os.path.join(ROOT, "include", "pcv_amd.h")).read()
+    return int(re.search(r"#define\s+PCV_ABI_VERSION\s+(\d+)", text).group(1))
+
+
+def _header_desc_fields():
     text = open(os.path.join(ROOT, "include", "pcv_amd.h")).read()
     body = text[text.index("typedef struct pcv_conv_desc {"):text.index("} pcv_conv_desc;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in re.findall(r"int32_t\s+([^;]+);", body):
         fields += [f.strip() for f in decl.split(",")]
+    return fields
+
+
+def test_conv_desc_matches_header_layout():
+    from pytorchcv_amd import _lib
+    from pytorchcv_amd._lib import ConvDesc
+    fields = _header_desc_fields()
+    assert fields[0] == "struct_size" and fields[-1] == "y_cpitch"
     assert fields == [f[0] for f in ConvDesc._fields_]
-    assert ctypes.sizeof(ConvDesc) == 4 * len(fields)
+    assert ctypes.sizeof(ConvDesc) == 4 * len(fields) == _lib.lib().pcv_conv_desc_size()
+    assert ConvDesc().struct_size == ctypes.sizeof(ConvDesc)            # filled in by the constructor
+
+
+def test_integration_stub_matches_header():
+    """INTEGRATION.md's reference-side ctypes stub declares exactly the header's descriptor (a stub one field short made the
+    library read the output pitch past the caller's struct in ABI version 1) and asserts the ABI version it was written for."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = md[md.index("class ConvDesc(ctypes.Structure):"):]
+    stub = stub[:stub.index(")]") + 2]
+    names = re.findall(r'"([A-Za-z_0-9]+)"', stub)
+    assert names == _header_desc_fields()
+    m = re.search(r"pcv_abi_version\(\) == (\d+) and L.pcv_conv_desc_size\(\) == ctypes.sizeof\(ConvDesc\)", md)
+    assert m and int(m.group(1)) == _header_abi_version()
+    call = md[md.index("d = ConvDesc("):]
+    call = call[:call.index("n = ctypes.c_size_t()")]
+    used = re.findall(r"\b([A-Za-z_0-9]+)=", call)
+    assert sorted(used) == sorted(_header_desc_fields()), "the stub's example call must set every field"
+
+
+def test_stale_descriptor_is_refused():
+    """A descriptor whose struct_size is not this library's sizeof(pcv_conv_desc) (a binding built against another layout)
+    is rejected by the host-side planning entry points instead of being read."""
+    from pytorchcv_amd import _lib
+    L = _lib.lib()
+    n = ctypes.c_size_t(0)
+    d = _desc()
+    assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    for bad in (0, ctypes.sizeof(_lib.ConvDesc) - 4, ctypes.sizeof(_lib.ConvDesc) + 4):
+        d.struct_size = bad
+        assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) != 0
+        assert L.pcv_dwconv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) != 0
+        assert L.pcv_conv1x1_pair_supported(ctypes.byref(d), ctypes.byref(d)) == 0
+        assert L.pcv_conv2d_maxpool_supported(ctypes.byref(d), 3, 2, 1, 0) == 0
+        assert L.pcv_mbconv_supported(None, ctypes.byref(d), ctypes.byref(d)) == 0
+
+
+def test_pytorchcv_import_path_is_the_drop_in():
+    """`from pytorchcv.model_provider import get_model` (reference model_provider.py:1364-1382) works unchanged and resolves
+    to this package: same registry, same classes, same weight store."""
+    import pytorchcv
+    from pytorchcv.model_provider import get_model
+    import pytorchcv_amd.model_provider as amd_mp
+    assert get_model is amd_mp.get_model
+    import pytorchcv.models.resnet as r
+    import pytorchcv_amd.models.resnet as ar
+    assert r is ar and r.resnet50 is ar.resnet50
+    from pytorchcv.models.common.model_store import load_model, calc_net_weight_count, get_model_file   # noqa: F401
+    import pytorchcv_amd.models.common.model_store as ams
+    assert load_model is ams.load_model
+    from pytorchcv.models.common.conv import ConvBlock, conv3x3_block                      # noqa: F401
+    with pytest.raises(ValueError, match="Unsupported model: nosuchnet"):
+        get_model("NoSuchNet")
+    net = get_model("resnet18")
+    assert calc_net_weight_count(net) == PARAM_COUNTS["resnet18"]
+    with pytest.raises(ImportError):
+        import pytorchcv.models.no_such_family                                            # noqa: F401
+    assert pytorchcv.set_compute_dtype is not None
 
 
 def _desc(**kw):
@@ -189,7 +258,8 @@ def test_synth_is_bit_stable():
     assert hashlib.sha1(synth_input(1, 3, 8, 8, seed=0).numpy().tobytes()).hexdigest() == \
         hashlib.sha1(synth_input(1, 3, 8, 8, seed=0).numpy().tobytes()).hexdigest()
     # frozen known answers: a change here silently invalidates every golden fixture
-    assert abs(float(u[0]) - 0.3419179320335388) < 1 or True
+    assert [float(v).hex() for v in u] == ['0x1.17f67e0000000p-1', '0x1.ff3ff40000000p-2', '0x1.d3dae80000000p-1', '0x1.6febca0000000p-1']
+    assert [float(v).hex() for v in n] == ['-0x1.a49a395560262p-1', '-0x1.09dee97fa3aa4p-2', '-0x1.e31e97057927cp-1']
     g, ids = util.model_golden("resnet18")
     assert ids == [16, 24, 31, 44] and g.shape == (4, 1000)
     assert len(n) == 3

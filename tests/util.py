@@ -11,6 +11,29 @@ GOLDEN = os.path.join(HERE, "golden")
 from pytorchcv_amd.synth import synth_state_dict, synth_input, hash_normal  # noqa: E402
 from cases import BLOCK_CASES, MODELS  # noqa: E402,F401
 
+import contextlib  # noqa: E402
+
+
+# defaults of the pcv_set_tuning switches the tests flip (restored on exit, also when the body raises)
+_TUNING_DEFAULTS = {"max_blocks": 0, "d3x3": -1, "tile": -1, "wstat": 1, "pair_pb": 2, "wpair": 3, "persist": 1}
+
+
+@contextlib.contextmanager
+def tuning(device=0, **switches):
+    """`with util.tuning(max_blocks=8): ...` - set library tuning switches for the body, restore their defaults after it.
+    `max_blocks=n` caps every persistent grid at n blocks so that a small fixture walks several tiles per block."""
+    from pytorchcv_amd import _lib
+    ctx = _lib.ctx_for(device)
+    L = _lib.lib()
+    try:
+        for k, v in switches.items():
+            _lib.check(L.pcv_set_tuning(ctx, k.encode(), int(v)), ctx)
+        yield
+    finally:
+        for k in switches:
+            _lib.check(L.pcv_set_tuning(ctx, k.encode(), _TUNING_DEFAULTS[k]), ctx)
+
+
 _blocks_npz = None
 _blocks_meta = None
 
