@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
+#include "d3x3_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
@@ -21,6 +22,8 @@
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
 IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
+D3X3_SHAPES(D3X3_DECLARE, PCV_BF16)
+D3X3_SHAPES(D3X3_DECLARE, PCV_F16)
 
 struct pcv_ctx {
     int device = 0;
@@ -29,7 +32,8 @@ struct pcv_ctx {
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
-    int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where it is instantiated (16-bit, s1/p1, Cin % 64 == 0), 0 = never
+    int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
+                                // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     int max_blocks = 0;         // test-only: cap on every persistent grid (0 = resident blocks), so that small fixtures walk several
                                 // tiles per block through the cross-tile pipelines (pcv_set_tuning("max_blocks", n))
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
@@ -336,6 +340,36 @@ static int enable_gconv(pcv_ctx* ctx) {
         }
     return PCV_OK;
 }
+// ---- 8-wave dense 3x3 kernel (d3x3_conv.hpp) ----------------------------------------------------------------------------
+struct D3Shape { int BM, BP, lds; const void* fn[2]; };       // fn[0] bf16, fn[1] fp16
+#define D3X3_ROW(DT, WC, WP, CBW, PBW)                                                                       \
+    {D3Cfg<WC, WP, CBW, PBW>::BM, D3Cfg<WC, WP, CBW, PBW>::BP, D3Cfg<WC, WP, CBW, PBW>::LDS,                 \
+     {reinterpret_cast<const void*>(d3x3_kernel<PCV_BF16, WC, WP, CBW, PBW>),                                \
+      reinterpret_cast<const void*>(d3x3_kernel<PCV_F16, WC, WP, CBW, PBW>)}},
+static const D3Shape kD3[] = {D3X3_SHAPES(D3X3_ROW, 0)};
+static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
+static int enable_d3x3(pcv_ctx* ctx) {
+    for (int i = 0; i < kD3Count; ++i)
+        for (int t = 0; t < 2; ++t)
+            HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
+    return PCV_OK;
+}
+// Tile shape for M pixels x Cout channels on `slots` CUs (one block each): rounds of the tile schedule x cycles per tile, a tile's
+// K-step costing the larger of its MFMA time (at the ~80 % the loop sustains) and its LDS-DMA time (~48 B/clk/CU from L2).
+static int pick_d3x3(long long M, int Cout, int nk, long long slots) {
+    int best = -1;
+    double best_cost = 0.0;
+    for (int i = 0; i < kD3Count; ++i) {
+        const long long nCh = (Cout + kD3[i].BM - 1) / kD3[i].BM, nP = (M + kD3[i].BP - 1) / kD3[i].BP;
+        const long long rounds = (nCh * nP + slots - 1) / slots;
+        const double mfma = (double)kD3[i].BM * kD3[i].BP / 32.0 / 0.8, dmac = (double)(kD3[i].BM + kD3[i].BP) * 128.0 / 48.0;
+        const double tile = nk * (mfma > dmac ? mfma : dmac) + (double)kD3[i].BM * kD3[i].BP / 16.0;
+        const double cost = (double)rounds * tile;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    }
+    return best;
+}
+
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
 static const int kStemLds = 7 * 64 * 64 + 2 * 768 * 16 + 3 * 2 * 64 * 16;     // weights + 2 patches + the pooled variant's row hand-down
 static int g_stem_blocks_per_cu[2];
@@ -568,6 +602,7 @@ int pcv_create(pcv_ctx** out, int device) {
     if (const char* e = std::getenv("PCV_AMD_PERSIST")) ctx->persist_mode = std::atoi(e);
     if (const char* e = std::getenv("PCV_AMD_PERSIST_NK")) ctx->persist_max_nk = std::atoi(e);
     int rc = enable_big_lds(ctx);
+    if (rc == PCV_OK) rc = enable_d3x3(ctx);
     if (rc == PCV_OK) rc = enable_gconv(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
@@ -843,6 +878,42 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
+    // ---- dense 3x3 / s1 / p1, 16 bit: the 8-wave kernel -----------------------------------------------------------------------
+    if (P.conv3 && !gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && d->act <= PCV_ACT_RELU6 && d->post_act <= PCV_ACT_RELU6 &&
+        scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        const int ypitch3 = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+        const unsigned long long ybytes3 = ((M64 - 1) * (unsigned long long)ypitch3 + d->Cout) * 2ull;
+        if (ypitch3 < d->Cout || (ypitch3 * 2) % 16 != 0)
+            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
+        if (ybytes3 >= 0x80000000ull)
+            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+        const long long slots = block_slots(ctx, 1);
+        int shape = ctx->use_d3x3 > 0 ? ctx->use_d3x3 - 1 : pick_d3x3((long long)M64, d->Cout, P.nk, slots);
+        if (shape >= kD3Count) shape = kD3Count - 1;
+        const D3Shape& S = kD3[shape];
+        D3Params q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
+        q.scale = scale; q.shift = shift;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes3;
+        q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
+        q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch3;
+        q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.nk = P.nk; q.slices = d->Cin / 64; q.Kpad = P.Kpad;
+        q.act = d->act; q.post_act = d->post_act;
+        q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
+        const long long nT = ((long long)((M64 + S.BP - 1) / S.BP)) * q.nChTiles;
+        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+        q.nTiles = (int)nT;
+        long long nb = slots < nT ? slots : nT;
+        nb = (nb + 7) / 8 * 8;
+        void* args[] = {&q};
+        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(512), args, (size_t)S.lds, (hipStream_t)stream));
+        return PCV_OK;
+    }
+
     const bool ragged = (d->Cout % 8 != 0) || (P.cout_blk % 8 != 0);
     int tile;
     if (ragged || d->out_dtype != d->dtype) tile = TILE_C128;

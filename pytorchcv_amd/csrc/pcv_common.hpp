@@ -67,17 +67,19 @@ template <int DT> __device__ __forceinline__ void store_elem(void* base, size_t 
 // ---- activations (reference: pytorchcv/models/common/activ.py) ------------------------------------------
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case PCV_ACT_RELU: return fmaxf(v, 0.f);                                   // activ.py:64
-        case PCV_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);                      // activ.py:81
+        case PCV_ACT_RELU: return v < 0.f ? 0.f : v;                               // activ.py:64 (NaN stays NaN, as in torch)
+        case PCV_ACT_RELU6: return v != v ? v : fminf(fmaxf(v, 0.f), 6.f);         // activ.py:81
         case PCV_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));        // activ.py:132 (v_rcp_f32: 1 ulp)
         case PCV_ACT_SWISH: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));      // activ.py:20-21
-        case PCV_ACT_HSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);      // activ.py:29-30
+        case PCV_ACT_HSIGMOID: return v != v ? v : fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);      // activ.py:29-30
         case PCV_ACT_HSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);    // activ.py:46-47
         default: return v;
     }
 }
-// The common activations (none / relu / relu6) are a clamp with launch-uniform bounds: two VALU ops, no branches in
-// the unrolled epilogues. Anything else takes the (uniform) slow branch once per 8-element group.
+// The common activations (none / relu / relu6) with launch-uniform codes: no activation is no instruction, ReLU is a compare +
+// select, ReLU6 a v_med3_f32 + a NaN patch - all NaN-PROPAGATING like torch's relu / hardtanh (v_max_f32 / v_med3_f32 alone
+// return the non-NaN operand, which would turn a NaN accumulator - corrupt weights, overflowed activations - into 0 / -inf
+// and hide it from every isfinite check downstream). One uniform branch per group, none per element.
 struct ActClamp {
     float lo, hi;
     bool slow;
@@ -92,8 +94,17 @@ __device__ __forceinline__ ActClamp make_act(int act) {
     return a;
 }
 template <int N> __device__ __forceinline__ void clampn(float (&v)[N], const ActClamp& a) {
+    if (a.code == PCV_ACT_NONE) return;
+    if (a.code == PCV_ACT_RELU) {
 #pragma unroll
-    for (int e = 0; e < N; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);
+        for (int e = 0; e < N; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];                 // NaN compares false: stays NaN
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float r = __builtin_amdgcn_fmed3f(v[e], 0.f, 6.f);
+            v[e] = v[e] != v[e] ? v[e] : r;
+        }
+    }
 }
 // the non-clamp activations: ONE uniform switch around a straight unrolled run per case (a switch per element costs eight
 // scalar compare/branch sequences in every epilogue group)
@@ -109,7 +120,7 @@ template <int N> __device__ __forceinline__ void apply_slow_actn(float (&v)[N], 
             break;
         case PCV_ACT_HSIGMOID:
 #pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+            for (int e = 0; e < N; ++e) v[e] = v[e] != v[e] ? v[e] : fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
             break;
         case PCV_ACT_HSWISH:
 #pragma unroll
@@ -124,18 +135,8 @@ template <int N> __device__ __forceinline__ void apply_actn(float (&v)[N], const
     if (a.slow) apply_slow_actn<N>(v, a.code);
     else clampn<N>(v, a);
 }
-__device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);
-}
-__device__ __forceinline__ void apply_act8(float (&v)[8], const ActClamp& a) {
-    if (a.slow) {
-        apply_slow_actn<8>(v, a.code);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], a.lo, a.hi);     // clamp in one VALU op
-    }
-}
+__device__ __forceinline__ void clamp8(float (&v)[8], const ActClamp& a) { clampn<8>(v, a); }
+__device__ __forceinline__ void apply_act8(float (&v)[8], const ActClamp& a) { apply_actn<8>(v, a); }
 
 // ---- exact unsigned division by a launch-time constant, n < 2^31 ----------------------------------------
 struct FastDiv {

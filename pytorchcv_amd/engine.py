@@ -193,17 +193,22 @@ class ConvRunner(object):
             ts += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
         return ts
 
-    def _state_key(self, dtype, cpitch):
-        # pad4 is part of the key: the stem packing depends on the parity of the left padding (TF-"same" mode changes it)
-        return (dtype, cpitch, self.pad4) + tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
+    def _state_key(self, dtype, cpitch, d: ConvDesc):
+        # everything the packed blob and the scale/shift arrays depend on besides the source tensors: physical channel counts
+        # (the fp32 classifier output keeps its logical width), output type, and the parity of the left padding (the stem
+        # packing depends on it; TF-"same" mode changes it per call)
+        return (dtype, cpitch, d.Cin, d.Cout, d.groups, d.out_dtype, d.pad_l & 1) + \
+            tuple((t.data_ptr(), t._version) if t is not None else None for t in self._sources())
 
-    def desc(self, x: NHWC, act, post_act, has_res, out_code=None, logits=False) -> ConvDesc:
+    def desc(self, x: NHWC, act, post_act, has_res, out_code=None, logits=False, pad4=None) -> ConvDesc:
+        """`pad4`: per-call (left, right, top, bottom) padding overriding the block's own (never stored on the runner)."""
         c = self.conv
         kh, kw = _pair(c.kernel_size)
         sh, sw = _pair(c.stride)
         dh, dw = _pair(c.dilation)
-        if self.pad4 is not None:               # ConvBlock's 4-tuple padding: (left, right, top, bottom)
-            pl, pr, pt, pb = [int(v) for v in self.pad4]
+        pad4 = pad4 if pad4 is not None else self.pad4
+        if pad4 is not None:                    # ConvBlock's 4-tuple padding: (left, right, top, bottom)
+            pl, pr, pt, pb = [int(v) for v in pad4]
         else:
             ph, pw = _pair(c.padding)
             pt = pb = ph
@@ -221,7 +226,7 @@ class ConvRunner(object):
     def prepare(self, x: NHWC, d: ConvDesc):
         if isinstance(c_mode := self.conv.padding_mode, str) and c_mode != "zeros":
             raise NotImplementedError("padding_mode {}".format(c_mode))
-        key = self._state_key(x.dtype, x.cpitch)
+        key = self._state_key(x.dtype, x.cpitch, d)
         if key == self._key:
             return
         dev = x.device
@@ -271,11 +276,9 @@ class ConvRunner(object):
     def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None, out=None, gate=None) -> NHWC:
         """`pad4`: explicit (left, right, top, bottom) zero padding for this call (the `F.pad` a unit applies in front of
         a padding-0 convolution, efficientnet.py:108-109,189-190,236-237); it stays inside the kernel's bounds checks."""
-        if pad4 is not None:
-            self.pad4 = tuple(int(v) for v in pad4)
         if self.bn is not None and self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
-        d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None, logits=out_fp32)
+        d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None, logits=out_fp32, pad4=pad4)
         self.prepare(x, d)
         return self._launch(x, d, residual, out, gate)
 
@@ -421,7 +424,7 @@ class ConvRunner(object):
             raise RuntimeError("squeezed_excite needs a plain 1x1 stride-1 convolution")
         d = self.desc(z, 0, 0, False)
         self.prepare(z, d)                                   # scale / shift of the folded BatchNorm (+ bias)
-        key = ("sq", self._key, w1.data_ptr(), w2.data_ptr(), w1._version, w2._version, b1._version, b2._version)
+        key = ("sq", self._key) + tuple((t.data_ptr(), t._version) for t in (w1, w2, b1, b2))
         if getattr(self, "_sq_key", None) != key:
             Cl, CP = c.out_channels, d.Cout
             w = c.weight.detach().float().reshape(Cl, -1)

@@ -79,23 +79,35 @@ def get_model_file(model_name, local_model_store_dir_path=os.path.join("~", ".to
     os.makedirs(root, exist_ok=True)
     zip_path = file_path + ".zip"
     _fetch("{}/releases/download/{}/{}.zip".format(imgclsmob_repo_url, tag, file_name), zip_path)
-    with zipfile.ZipFile(zip_path) as zf:
-        zf.extractall(root)
-    os.remove(zip_path)
-    if _sha1_ok(file_path, sha1_hash):
+    # only the one expected member leaves the archive, under its expected name (no path-traversal names, no other files),
+    # into a temporary file that becomes the model file only after its SHA-1 has been verified
+    tmp_path = file_path + ".part"
+    try:
+        with zipfile.ZipFile(zip_path) as zf:
+            if file_name not in zf.namelist():
+                raise ValueError("Downloaded archive does not contain {}".format(file_name))
+            with zf.open(file_name) as src, open(tmp_path, "wb") as dst:
+                for chunk in iter(lambda: src.read(1 << 20), b""):
+                    dst.write(chunk)
+    finally:
+        os.remove(zip_path)
+    if _sha1_ok(tmp_path, sha1_hash):
+        os.replace(tmp_path, file_path)
         return file_path
+    os.remove(tmp_path)
     raise ValueError("Downloaded file has different hash. Please try again.")
 
 
 def load_model(net, file_path, ignore_extra=True):
     """Load a `.pth` state dict; with `ignore_extra`, entries the net does not own are dropped first."""
     import torch
+    # the released checkpoints are plain tensor state dicts: the restricted unpickler is all they need (the reference passes
+    # weights_only=False, model_store.py:325, which would run arbitrary pickle code from a downloaded file)
+    state = torch.load(file_path, weights_only=True, map_location="cpu")
     if ignore_extra:
-        state = torch.load(file_path, weights_only=False)
         own = net.state_dict()
-        net.load_state_dict({k: v for k, v in state.items() if k in own})
-    else:
-        net.load_state_dict(torch.load(file_path))
+        state = {k: v for k, v in state.items() if k in own}
+    net.load_state_dict(state)
 
 
 def download_model(net, model_name, local_model_store_dir_path=os.path.join("~", ".torch", "models"), ignore_extra=True):

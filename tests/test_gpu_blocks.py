@@ -133,7 +133,7 @@ _CONV3_SHAPES = [
 
 
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["generic", "d3x3"])
+@pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(8)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
 def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device):
@@ -141,8 +141,9 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv3x3_block
     from oracle import refnet
-    if kernel == "d3x3" and dtype == "fp32":
+    if kernel != "generic" and dtype == "fp32":
         pytest.skip("the 8-wave dense 3x3 kernel is 16-bit only; fp32 takes the generic implicit GEMM")
+    d3 = 0 if kernel == "generic" else (-1 if kernel.endswith("auto") else int(kernel.split(":")[1]) + 1)    # forced tile shape
     N, C, Cout, H, W, use_res = shape
     blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
     sd = util.synth_state_dict(blk.state_dict(), seed=77)
@@ -150,10 +151,18 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
     x = util.synth_input(N, C, H, W, seed=21)
     res = util.synth_input(N, Cout, H, W, seed=22) if use_res else None
-    with torch.no_grad(), util.tuning(max_blocks=grid, d3x3=1 if kernel == "d3x3" else 0):
+    with torch.no_grad():
         xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
         rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
-        y = engine.to_nchw(blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)).cpu()
+        with util.tuning(max_blocks=grid, d3x3=d3):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        if kernel != "generic":
+            # same K order, same MFMA sequence per accumulator, same epilogue arithmetic: bit-identical to the generic kernel
+            with util.tuning(d3x3=0):
+                yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+            assert torch.equal(yh.t, yg.t), "{} differs from the generic implicit GEMM in {} elements".format(
+                kernel, int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
     q = refnet.Quant(None if dtype == "fp32" else dtype)
     ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None,
                             post_act="relu" if use_res else None)
@@ -457,3 +466,29 @@ def test_gated_conv_and_gated_pair(shape, cm, c1, dtype, grid, cuda_device):
     d = (y1.t.float() - ref).abs()
     tol = (2.0 ** -7 if dtype == "bf16" else 2.0 ** -10)
     assert bool((d <= tol * (plain.t.float().abs() * gate[:, None, None, :] + ref.abs() + 1.0)).all()), float(d.max())
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("act", [None, "relu", "relu6", "hswish"])
+def test_nan_in_is_nan_out(act, dtype, cuda_device):
+    """torch's relu / relu6 (hardtanh) propagate NaN (activ.py:64,81 are nn.ReLU / nn.ReLU6): a NaN input pixel gives NaN at
+    exactly the outputs whose receptive field holds it, for every epilogue activation - a clamp built on v_max / v_med3 alone
+    would return 0 / -inf there and hide corrupt weights or overflowed activations from downstream isfinite checks."""
+    import pytorchcv_amd
+    from pytorchcv_amd.models.common.conv import conv3x3_block, dwconv3x3_block
+    from pytorchcv_amd.models.common.activ import create_activation_layer
+    for ctor in (conv3x3_block, dwconv3x3_block):
+        blk = ctor(in_channels=64, out_channels=64, activation=(lambda: create_activation_layer(act)) if act else None).eval()
+        blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=5))
+        blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+        x = util.synth_input(1, 64, 9, 9, seed=6)
+        x[0, 3, 4, 5] = float("nan")
+        with torch.no_grad():
+            y = blk(x.to(cuda_device)).cpu()
+        nan = torch.isnan(y)
+        want = torch.zeros_like(nan)
+        if ctor is conv3x3_block:
+            want[0, :, 3:6, 4:7] = True             # every output channel sums over input channel 3
+        else:
+            want[0, 3, 3:6, 4:7] = True             # depthwise: channel 3 only
+        assert torch.equal(nan, want), "{}: {} NaN outputs, expected {}".format(ctor.__name__, int(nan.sum()), int(want.sum()))

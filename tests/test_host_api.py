@@ -263,3 +263,44 @@ def test_synth_is_bit_stable():
     g, ids = util.model_golden("resnet18")
     assert ids == [16, 24, 31, 44] and g.shape == (4, 1000)
     assert len(n) == 3
+
+
+def test_weight_store_download_extracts_only_the_expected_member(tmp_path, monkeypatch):
+    """The download branch with a stand-in for the HTTP fetch: only the expected `.pth` leaves the archive (a path-traversal
+    member and a stray file stay inside it), it becomes the model file only after its SHA-1 matched, and a wrong hash leaves
+    nothing behind."""
+    import zipfile
+    from pytorchcv_amd.models.common import model_store as ms
+    from pytorchcv_amd.model_provider import get_model
+    net = get_model("resnet10").eval()
+    sd = util.synth_state_dict(net.state_dict(), seed=8)
+    src = tmp_path / "src.pth"
+    torch.save(sd, str(src))
+    blob = open(src, "rb").read()
+    sha1 = hashlib.sha1(blob).hexdigest()
+    name = "resnet10-1253-{}.pth".format(sha1[:8])
+    store = tmp_path / "store"
+    urls = []
+
+    def fake_fetch(url, path, retries=5):
+        urls.append(url)
+        with zipfile.ZipFile(path, "w") as zf:
+            zf.writestr("../evil.txt", b"escaped")
+            zf.writestr("stray.bin", b"stray")
+            zf.writestr(name, blob)
+        return path
+    monkeypatch.setattr(ms, "_fetch", fake_fetch)
+    monkeypatch.setattr(ms, "get_model_metainfo_dict", lambda: {"resnet10": (5418792, "1253", sha1, "v0.0.9")})
+    got = ms.get_model_file("resnet10", str(store))
+    assert got == str(store / name) and urls and urls[0].endswith("/releases/download/v0.0.9/{}.zip".format(name))
+    assert sorted(os.listdir(store)) == [name]                    # nothing else was unpacked, the zip is gone
+    assert not (tmp_path / "evil.txt").exists()
+    ms.load_model(net, got)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    # wrong hash in the table: refused, no partial file kept
+    os.remove(got)
+    monkeypatch.setattr(ms, "get_model_metainfo_dict", lambda: {"resnet10": (5418792, "1253", sha1[:8] + "0" * 32, "v0.0.9")})
+    with pytest.raises(ValueError, match="different hash"):
+        ms.get_model_file("resnet10", str(store))
+    assert os.listdir(store) == []

@@ -13,7 +13,9 @@ LAYERS = [  # (N, Cin, Cout, H, k, stride, groups, residual)
     (256, 64, 64, 56, 3, 1, 1, False), (256, 128, 128, 28, 3, 1, 1, False), (256, 256, 256, 14, 3, 1, 1, False),
     (256, 512, 512, 7, 3, 1, 1, False),
 ]
-VARIANTS = {"generic": {"conv3": 0}, "conv3": {"conv3": 1, "c3flags": 0}}
+SHAPES = ["256x256", "256x224", "256x208", "256x112", "128x416", "128x224", "64x448", "64x256"]     # d3x3_inst.hpp order
+VARIANTS = {"generic": {"d3x3": 0}, "auto": {"d3x3": -1}}
+VARIANTS.update({"d3:" + n: {"d3x3": i + 1} for i, n in enumerate(SHAPES)})
 if len(sys.argv) > 1:
     exec(open(sys.argv[1]).read())       # a file may redefine LAYERS / VARIANTS
 
@@ -34,7 +36,7 @@ for (N, C, Co, H, k, s, g, res) in LAYERS:
         for v, t in VARIANTS.items():
             tune(t); blk(x, residual=r)
         torch.cuda.synchronize()
-        for rnd in range(7):
+        for rnd in range(5):
             for v, t in VARIANTS.items():
                 tune(t)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,5 +46,7 @@ for (N, C, Co, H, k, s, g, res) in LAYERS:
                 e1.record(); torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / 5 * 1e3)
     flops = 2.0 * N * Ho * Ho * Co * (C // g) * k * k
-    print("N%d %dx%d C%d->%d k%d s%d g%d%s:" % (N, H, H, C, Co, k, s, g, " +res" if res else ""),
-          "  ".join("%s %.1f us (%.0f TF)" % (v, statistics.median(t), flops / statistics.median(t) / 1e6) for v, t in times.items()), flush=True)
+    print("N%d %dx%d C%d->%d k%d s%d g%d%s:" % (N, H, H, C, Co, k, s, g, " +res" if res else ""), flush=True)
+    for v, t in times.items():
+        print("    %-12s %7.1f us  %6.0f TF   (min %.1f)" % (v, statistics.median(t), flops / statistics.median(t) / 1e6, min(t)), flush=True)
+tune({"d3x3": -1})
