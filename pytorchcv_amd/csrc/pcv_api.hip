@@ -34,6 +34,7 @@ struct pcv_ctx {
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
+    unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
     int max_blocks = 0;         // test-only: cap on every persistent grid (0 = resident blocks), so that small fixtures walk several
                                 // tiles per block through the cross-tile pipelines (pcv_set_tuning("max_blocks", n))
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
@@ -342,31 +343,38 @@ static int enable_gconv(pcv_ctx* ctx) {
 }
 // ---- 8-wave dense 3x3 kernel (d3x3_conv.hpp) ----------------------------------------------------------------------------
 struct D3Shape { int BM, BP, lds; const void* fn[2]; };       // fn[0] bf16, fn[1] fp16
-#define D3X3_ROW(DT, WC, WP, CBW, PBW)                                                                       \
-    {D3Cfg<WC, WP, CBW, PBW>::BM, D3Cfg<WC, WP, CBW, PBW>::BP, D3Cfg<WC, WP, CBW, PBW>::LDS,                 \
-     {reinterpret_cast<const void*>(d3x3_kernel<PCV_BF16, WC, WP, CBW, PBW>),                                \
-      reinterpret_cast<const void*>(d3x3_kernel<PCV_F16, WC, WP, CBW, PBW>)}},
+#define D3X3_ROW(DT, WC, WP, CBW, PBW, KS)                                                                   \
+    {D3Cfg<WC, WP, CBW, PBW, KS>::BM, D3Cfg<WC, WP, CBW, PBW, KS>::BP, D3Cfg<WC, WP, CBW, PBW, KS>::LDS,     \
+     {reinterpret_cast<const void*>(d3x3_kernel<PCV_BF16, WC, WP, CBW, PBW, KS>),                            \
+      reinterpret_cast<const void*>(d3x3_kernel<PCV_F16, WC, WP, CBW, PBW, KS>)}},
 static const D3Shape kD3[] = {D3X3_SHAPES(D3X3_ROW, 0)};
 static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
+static const int kD3Auto = 9;                                 // shapes the cost model may pick (the rest are A/B variants)
 static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
     return PCV_OK;
 }
-// Tile shape for M pixels x Cout channels on `slots` CUs (one block each): rounds of the tile schedule x cycles per tile, a tile's
-// K-step costing the larger of its MFMA time (at the ~80 % the loop sustains) and its LDS-DMA time (~48 B/clk/CU from L2).
+// Tile shape for M pixels x Cout channels on `slots` CUs (one block each): rounds of the tile schedule x cycles per tile. A K-step
+// costs its MFMA time (at the ~85 % issue efficiency of a section) PLUS its LDS-DMA time - in-kernel stamps show the two
+// serialised: the L2 -> LDS path delivers ~37 B/clk/CU and the issuing waves block on it - plus four barrier intervals.
+// Returns -1 where the generic 4-wave kernel is the better choice: 64-channel layers (two thirds of a K-step's bytes are
+// re-fetched activation rows: 106 vs 95 us on ResNet-50's 56x56x64 layer) and launches that cannot fill a quarter of the CUs.
 static int pick_d3x3(long long M, int Cout, int nk, long long slots) {
+    if (Cout <= 64) return -1;
     int best = -1;
     double best_cost = 0.0;
-    for (int i = 0; i < kD3Count; ++i) {
+    long long best_tiles = 0;
+    for (int i = 0; i < kD3Auto; ++i) {
         const long long nCh = (Cout + kD3[i].BM - 1) / kD3[i].BM, nP = (M + kD3[i].BP - 1) / kD3[i].BP;
         const long long rounds = (nCh * nP + slots - 1) / slots;
-        const double mfma = (double)kD3[i].BM * kD3[i].BP / 32.0 / 0.8, dmac = (double)(kD3[i].BM + kD3[i].BP) * 128.0 / 48.0;
-        const double tile = nk * (mfma > dmac ? mfma : dmac) + (double)kD3[i].BM * kD3[i].BP / 16.0;
+        const double mfma = (double)kD3[i].BM * kD3[i].BP / 32.0 / 0.85, dmac = (double)(kD3[i].BM + kD3[i].BP) * 128.0 / 37.0;
+        const double tile = nk * (mfma + dmac + 520.0) + (double)kD3[i].BM * kD3[i].BP / 16.0;
         const double cost = (double)rounds * tile;
-        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_tiles = nCh * nP; }
     }
+    if (best_tiles * 4 < slots) return -1;
     return best;
 }
 
@@ -630,6 +638,8 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
+    else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;
+    else if (k == "dbg_hi") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);
     else if (k == "wstat") ctx->use_wstat = value;
     else return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: unknown key " + k);
     return PCV_OK;
@@ -879,8 +889,13 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return PCV_OK;
     }
     // ---- dense 3x3 / s1 / p1, 16 bit: the 8-wave kernel -----------------------------------------------------------------------
+    int d3shape = -1;
     if (P.conv3 && !gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && d->act <= PCV_ACT_RELU6 && d->post_act <= PCV_ACT_RELU6 &&
         scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        d3shape = ctx->use_d3x3 > 0 ? std::min(ctx->use_d3x3 - 1, kD3Count - 1)
+                                    : pick_d3x3((long long)M64, d->Cout, P.nk, (long long)ctx->num_cu);
+    }
+    if (d3shape >= 0) {
         const int ypitch3 = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
         const unsigned long long ybytes3 = ((M64 - 1) * (unsigned long long)ypitch3 + d->Cout) * 2ull;
         if (ypitch3 < d->Cout || (ypitch3 * 2) % 16 != 0)
@@ -888,9 +903,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         if (ybytes3 >= 0x80000000ull)
             return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
         const long long slots = block_slots(ctx, 1);
-        int shape = ctx->use_d3x3 > 0 ? ctx->use_d3x3 - 1 : pick_d3x3((long long)M64, d->Cout, P.nk, slots);
-        if (shape >= kD3Count) shape = kD3Count - 1;
-        const D3Shape& S = kD3[shape];
+        const D3Shape& S = kD3[d3shape];
         D3Params q;
         std::memset(&q, 0, sizeof(q));
         q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
@@ -907,6 +920,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         const long long nT = ((long long)((M64 + S.BP - 1) / S.BP)) * q.nChTiles;
         if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
         q.nTiles = (int)nT;
+        q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
         long long nb = slots < nT ? slots : nT;
         nb = (nb + 7) / 8 * 8;
         void* args[] = {&q};
