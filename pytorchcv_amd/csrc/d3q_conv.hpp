@@ -1,0 +1,500 @@
+// d3q_conv.hpp - dense 3x3 / stride 1 / pad 1 convolution on gfx950 MFMA with filter-ROW reuse of the activation operand.
+// The MFMA-bound class of the path (ResNet-50: 16 layers, 48 % of the MACs).
+//
+// Replaces: nn.Conv2d(3x3, stride 1, padding 1) + nn.BatchNorm2d(eval) + activation of ConvBlock.forward
+//           (reference pytorchcv/models/common/conv.py:278-286) at `conv3x3_block` call sites
+//           (resnet.py:49,56,120-127 - ResBlock / ResBottleneck.conv2 - vgg.py, preresnet.py), plus the residual add +
+//           ReLU of basic-block units (resnet.py:227-228) in the epilogue.
+//
+// GEMM view: Y^T[ch, pixel] = sum_k Wp[ch, k] X[pixel, k], k = (filter row r, 64-channel slice c, filter column q) - the
+// packed blob of `plan_conv`'s `conv3` order. A = weights (one 128-byte row per channel and K-step), B = pixels.
+//
+// What the stamps of the first 8-wave kernel (d3x3, im2col gather per K-step) showed: a K-step's LDS-DMA (58 KB for a
+// 256 x 208 tile) passes the texture path at ~1 KB per 16 clk per CU and the issuing waves block on it - DMA time and MFMA
+// time ADD UP (3 400 cycles per K-step for 1 664 of MFMA), and a 2-deep ring leaves no interval in which pieces can be
+// issued without standing in front of somebody's MFMAs. Two thirds of those bytes are the same input rows fetched again for
+// the next filter column. So here:
+//   * B is staged ONCE per group g = (r, c): the BP + 2 input rows of the flat pixel range [P0 - 1, P0 + BP] shifted by
+//     (r - 1) image rows (vertical padding = per-row out-of-range DMA offsets, as before). The three K-steps q = 0, 1, 2 of
+//     the group read it at row offsets 0, 1, 2. Horizontal padding - the left neighbour of a pixel in column 0 is the
+//     previous image row's last pixel in this flat range - is applied at fragment-read time: a lane whose output pixel sits
+//     in column 0 (q = 0) or W - 1 (q = 2) reads a zero row instead (address select, two VALU per fragment; q = 1 none).
+//     DMA bytes per K-step: 256 x 208 tile 58 -> 41 KB, 128 x 416 68 -> 34 KB, 64 x 448 64 -> 27 KB.
+//   * The LDS this frees holds a 3-deep ring of weight tiles (A): the pieces of K-step k + 2 and of group g + 1 are issued
+//     during K-step k by every wave in the read section it has anyway, two K-steps ahead of their first use; `s_waitcnt
+//     vmcnt(N)` with N = the pieces issued during the current K-step, raw `s_barrier`, never a drain.
+//   * 512 threads, one block per CU; waves 0-3 and 4-7 (one of each per SIMD) run one barrier interval apart - while one
+//     group reads fragments, the other's MFMAs own the matrix pipe (MI355X_MICROARCH.md, "Two waves per SIMD"). KS K-halves
+//     per section: a K-step is 4 (KS = 1) or 2 (KS = 2) barrier intervals.
+//   * Tile shapes chosen by the host so that the tile count fills whole rounds of the CUs (wave tiles of 7 or 13 pixel
+//     blocks: 112 / 208 / 416 / 448-pixel tiles).
+//
+// Barrier/visibility rules (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
+//   RAW  a wave waits for ITS pieces of K-step k + 1 / group g + 1 (counted vmcnt) before the barrier that ends K-step k;
+//        their first read is issued after that barrier.
+//   WAR  every fragment read is retired (lgkmcnt(0)) before the barrier that ends its interval; the A slot of K-step k - 1
+//        and the B slot of group g - 1 are re-filled from K-step k / 3 g on, after both groups' last reads of them.
+#pragma once
+#include <type_traits>
+#include "pcv_common.hpp"
+#include "igemm_conv.hpp"     // Mma<DT>, FastDiv
+
+struct D3Params {
+    const void* x;          // NHWC [N,H,W,Cin], dense
+    const void* w;          // packed weights [rows][Kpad], K = (r, slice, q), rows in MFMA order
+    const void* res;        // residual NHWC [M, Cout] or null
+    void* y;                // NHWC [M, Ypitch]
+    const float* scale;     // [Cout] fp32, never null
+    const float* shift;
+    uint32_t x_bytes, w_bytes, y_bytes, res_bytes;
+    int M;                  // N*H*W
+    int Cout, Ypitch;
+    int H, W, Cin, HW;
+    FastDiv div_hw, div_w;
+    int nk;                 // K-steps = 9 * Cin / 64 (a multiple of 3)
+    int slices;             // Cin / 64
+    int Kpad;
+    int act, post_act;
+    int nChTiles, nTiles;
+    uint32_t* dbg;          // diagnostic builds only (-DD3X3_STAMPS)
+};
+
+// In-kernel stamps (cdna_hip_programming.md section 7): a diagnostic build (-DD3X3_STAMPS) times ONE section per K-step - the
+// stamp that opens it and the stamp that closes it, s_memtime low words written into the lanes of one VGPR per wave - and
+// rotates the section from K-step to K-step (steps 4..30: every section three times). Stamp points sit behind a barrier or an
+// explicit lgkmcnt(0), where no LDS read is outstanding (s_memtime returns through lgkmcnt). The product build compiles none
+// of this.
+#ifdef D3X3_STAMPS
+#define D3_STAMP(slot)                                                                                     \
+    do {                                                                                                   \
+        const int q__ = s - 4;                                                                             \
+        if (q__ >= -1 && q__ < 27) {                                                                       \
+            const int sel__ = (q__ + 9) % 9;                                                               \
+            int l__ = -1;                                                                                  \
+            if (q__ >= 0 && (slot) == sel__) l__ = 2 * q__ + 1;                                            \
+            else if (q__ >= 0 && sel__ > 0 && (slot) == sel__ - 1) l__ = 2 * q__;                          \
+            else if ((slot) == 8 && (q__ + 1) % 9 == 0 && q__ + 1 < 27) l__ = 2 * (q__ + 1);               \
+            if (l__ >= 0) {                                                                                \
+                const uint64_t t__ = __builtin_amdgcn_s_memtime();                                         \
+                const int v__ = __builtin_amdgcn_readfirstlane((int)(uint32_t)t__);                        \
+                const int i__ = __builtin_amdgcn_readfirstlane(l__);                                       \
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(stamps) : "s"(v__), "s"(i__) : "m0"); \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+#else
+#define D3_STAMP(slot) do { } while (0)
+#endif
+
+// WC x WP: wave grid (channels x pixels), 8 waves. CBW / PBW: 16-row blocks per wave (channels / pixels).
+// KS: K-halves (32 elements each) per read / MFMA section.
+template <int WC, int WP, int CBW, int PBW, int KS> struct D3Cfg {
+    static constexpr int BM = 16 * CBW * WC;                 // channel rows per block tile
+    static constexpr int BP = 16 * PBW * WP;                 // pixel rows per block tile
+    static constexpr int NPA = BM / 8;                       // 1 KB DMA pieces (8 rows x 128 B) of one weight tile
+    static constexpr int WLW = NPA / 8;                      // ... per wave (every wave loads)
+    static constexpr int BROWS = (BP + 2 + 7) / 8 * 8;       // rows of one activation tile: flat pixels P0 - 1 .. P0 + BP, padded
+    static constexpr int NPB = BROWS / 8;
+    static constexpr int XLW = (NPB + 7) / 8;                // activation pieces per wave per group (pieces past the tile: zeros into pad rows)
+    static constexpr int NB0 = (XLW + 1) / 2, NB1 = XLW / 2; // ... issued during the group's K-steps q = 0 and q = 1
+    static constexpr int ASZ = BM * 128;                     // bytes of one A slot
+    static constexpr int BSZ = NPB * 1024;                   // bytes of one B slot
+    static constexpr int NSA = 3;
+    static constexpr int ZOFF = NSA * ASZ + 2 * BSZ;         // 128 zero bytes: the row a horizontally padded tap reads
+    static constexpr int DUMP = ZOFF + 128;                  // 1 KB: where the (8 XLW - NPB) surplus pieces of a group land (every wave
+                                                             // issues the same number of pieces so that the vmcnt counts are constants)
+    static constexpr int LDS = DUMP + 1024;
+    static_assert(WC * WP == 8, "eight waves");
+    static_assert(KS == 1 || KS == 2, "one or two K-halves per section");
+    static_assert(NPA % 8 == 0 && CBW % 2 == 0, "weight pieces split evenly over the waves; channel pairs per wave");
+    static_assert(LDS <= 160 * 1024, "three weight tiles + two activation tiles must fit the LDS");
+    static_assert(XLW <= 10, "row masks of the activation pieces are packed 3 bits each into one register");
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The whole persistent loop of one wave group (GRP 0: waves 0-3, GRP 1: waves 4-7, one barrier interval behind). The two
+// instantiations are separate straight-line loop nests (no per-interval group branches for the register allocator to join).
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, int GRP>
+__device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const int wave) {
+    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
+    constexpr int BM = G::BM, BP = G::BP, WLW = G::WLW, XLW = G::XLW, NSA = G::NSA;
+    typedef typename Mma<DT>::frag frag;
+    typedef __attribute__((address_space(3))) char lds_char;
+
+    const int lane = threadIdx.x & 63;
+    const int wc = wave / WP, wp = wave % WP;
+    const int lrow = lane >> 3;
+    const int cs = (lane & 7) ^ lrow;                         // K-chunk this lane fetches (source-side swizzle)
+    const int fr = lane & 15, fq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)PCV_LDS(smem));
+
+    // ---- this block's tiles: [tile0, tend) of its XCD's contiguous range, stride = blocks per XCD -------------------------
+    const int perXcd = (p.nTiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int tstride = gridDim.x >> 3;                       // host guarantees gridDim.x % 8 == 0
+    const int tile0 = xcd * perXcd + (int)(blockIdx.x >> 3);
+    const int tend = min(p.nTiles, (xcd + 1) * perXcd);
+    if (tile0 >= tend) return;                                 // (whole block: the tile range does not depend on the wave)
+    const int nMine = (tend - tile0 + tstride - 1) / tstride;
+    const int nk = p.nk;
+    const int ngrp = nk / 3;                                   // groups (r, c) per tile
+    const int K_total = nMine * nk;                           // K-steps this block walks
+    const int G_total = nMine * ngrp;                         // groups
+
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res != nullptr ? p.res_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    // Activations: the descriptor's base sits one image row BELOW x, so that the (wave-uniform, unsigned) scalar offset of a
+    // group, (r * W * Cin + 64 c) elements, reaches the row above a pixel with r = 0. num_records covers the per-lane offset
+    // of any pixel plus the largest scalar offset (whether or not the range check adds the scalar offset, a valid lane passes
+    // it); a row that must read as zeros gets the offset 2^31, beyond num_records either way (the host keeps
+    // x_bytes + 2 rows below 2^31).
+    const uint32_t rowBytes = (uint32_t)(p.W * p.Cin * 2);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x)) - rowBytes, 0, p.x_bytes + 2u * rowBytes, 0x00020000);
+
+    // ---- DMA side ----------------------------------------------------------------------------------------------------------------
+    // weights: K-step `la_k` of tile `la_tile` goes to A slot la_slot; wave w owns pieces 8 i + w (rows 8 (8 i + w) + lrow)
+    int la_tile = tile0, la_k = 0, la_slot = 0, la_g = 0;      // la_g: global index of the next K-step to issue
+    uint32_t woff0 = 0;
+    auto setup_a = [&](int t) __attribute__((always_inline)) {
+        const int chTile = t % p.nChTiles;
+        woff0 = (uint32_t)(((chTile * BM + 8 * wave + lrow) * p.Kpad + cs * 8) * 2);     // rows past the blob: out of range -> zeros
+    };
+    const uint32_t wstep = (uint32_t)(64 * p.Kpad * 2);        // 8 pieces x 8 rows further down the blob
+    // pieces [I0, I1) of the weight tile; `advance_a` steps to the next K-step once all WLW are out
+    auto dma_a = [&](auto I0c, auto I1c) __attribute__((always_inline)) {
+        constexpr int I0 = decltype(I0c)::value, I1 = decltype(I1c)::value;
+#pragma unroll
+        for (int i = I0; i < I1; ++i) {
+            const uint32_t dst = lds0 + (uint32_t)(la_slot * G::ASZ + (8 * i + wave) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_char*)(size_t)dst, 16, woff0 + i * wstep, la_k * 128, 0, 0);
+        }
+    };
+    auto advance_a = [&]() __attribute__((always_inline)) {
+        ++la_g;
+        la_slot = la_slot + 1 == NSA ? 0 : la_slot + 1;
+        if (++la_k == nk) {
+            la_k = 0;
+            la_tile += tstride;
+            if (la_tile < tend) setup_a(la_tile);
+        }
+    };
+    // activations: group (lb_r, lb_c) of tile `lb_tile` goes to B slot lb_slot; wave w owns pieces 8 j + w: LDS rows
+    // u = 8 (8 j + w) + lrow <-> flat pixel P0 + u - 1, input pixel = that pixel shifted by (lb_r - 1) image rows
+    int lb_tile = tile0, lb_r = 0, lb_c = 0, lb_slot = 0, lb_g = 0;
+    uint32_t pbv[XLW];             // byte offset of the pixel itself (+ this lane's chunk), or 0x80000000 for a row outside [0, M) / the tile
+    uint32_t vmask = 0;            // 3 bits per piece: image row ho + r - 1 exists, r = 0, 1, 2
+    auto setup_b = [&](int t) __attribute__((always_inline)) {
+        const int tileP0 = (t / p.nChTiles) * BP;
+        vmask = 0;
+#pragma unroll
+        for (int j = 0; j < XLW; ++j) {
+            const int u = 8 * (8 * j + wave) + lrow;
+            const int m = tileP0 + u - 1;
+            uint32_t off = 0x80000000u, vm = 0;
+            if (u < BP + 2 && m >= 0 && m < p.M) {
+                const uint32_t n = fastdiv((uint32_t)m, p.div_hw);
+                const uint32_t ho = fastdiv((uint32_t)m - n * (uint32_t)p.HW, p.div_w);
+                off = (uint32_t)((m * p.Cin + cs * 8) * 2);
+                vm = (ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u);
+            }
+            pbv[j] = off;
+            vmask |= vm << (3 * j);
+        }
+    };
+    // pieces [J0, J1) of the group
+    auto dma_b = [&](auto J0c, auto J1c) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
+        const uint32_t soff = (uint32_t)(lb_r * p.W * p.Cin + lb_c * 64) * 2u;
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            const uint32_t dst = lds0 + (uint32_t)(8 * j + wave < G::NPB ? NSA * G::ASZ + lb_slot * G::BSZ + (8 * j + wave) * 1024 : G::DUMP);
+            const int t = __builtin_amdgcn_sbfe((int)vmask, 3 * j + lb_r, 1);                  // -1: the image row exists
+            const uint32_t voff = ((uint32_t)t & pbv[j]) | (~(uint32_t)t & 0x80000000u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_char*)(size_t)dst, 16, voff, soff, 0, 0);
+        }
+    };
+    auto advance_b = [&]() __attribute__((always_inline)) {   // group order inside a tile: (r, c), c fastest
+        ++lb_g;
+        lb_slot ^= 1;
+        if (++lb_c == p.slices) {
+            lb_c = 0;
+            if (++lb_r == 3) {
+                lb_r = 0;
+                lb_tile += tstride;
+                if (lb_tile < tend) setup_b(lb_tile);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> C0;
+    typedef std::integral_constant<int, G::NB0> CB0;
+    typedef std::integral_constant<int, XLW> CBN;
+    // weight pieces issued behind the first / second read section of a K-step (KS == 2 has one section)
+    constexpr int WA0 = KS == 2 ? WLW : (WLW + 1) / 2;
+    typedef std::integral_constant<int, WA0> CA0;
+    typedef std::integral_constant<int, WLW> CAN;
+
+    // ---- compute side -------------------------------------------------------------------------------------------------------
+    f32x4 acc[CBW][PBW];
+    frag a[KS][CBW], b[KS][PBW];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CBW; ++i)
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // fragment addresses: A row = wave's channel row, B row = wave's pixel row + 1 + (q - 1); the swizzle key is the row & 7
+    const uint32_t afrag = lds0 + (uint32_t)((wc * 16 * CBW + fr) * 128);
+    const uint32_t brow0 = (uint32_t)(wp * 16 * PBW + fr);
+    uint32_t hm0 = 0, hm2 = 0;     // bit j: this lane's output pixel of block j is in image column 0 / W - 1 (set per tile)
+    auto setup_masks = [&](int t) __attribute__((always_inline)) {
+        const int m0 = (t / p.nChTiles) * BP + wp * 16 * PBW + fr;
+        hm0 = hm2 = 0;
+#pragma unroll
+        for (int j = 0; j < PBW; ++j) {
+            const uint32_t m = (uint32_t)(m0 + 16 * j);
+            const uint32_t wo = m - fastdiv(m, p.div_w) * (uint32_t)p.W;              // (n H + ho) W + wo = m
+            hm0 |= (wo == 0u ? 1u : 0u) << j;
+            hm2 |= (wo + 1u == (uint32_t)p.W ? 1u : 0u) << j;
+        }
+    };
+    // section h (of 2 / KS) of K-step (A slot sa, B slot sb, filter column Q): K-halves h * KS .. h * KS + KS - 1.
+    // Fragment i / j sits i / j * 2048 bytes behind the wave's first row: pointer arithmetic, so that the constant folds into the
+    // ds_read offset field. A horizontally padded tap selects the BASE (zero row - j * 2048) per lane, the offset stays immediate.
+    typedef const __attribute__((address_space(3))) char* lds_cptr;
+    typedef const __attribute__((address_space(3))) frag* lds_fptr;
+    auto reads = [&](int sa, int sb, auto Qc, int h) __attribute__((always_inline)) {
+        constexpr int Q = decltype(Qc)::value;
+        const uint32_t abase = afrag + (uint32_t)(sa * G::ASZ);
+        const uint32_t brow = brow0 + Q;
+        const uint32_t bbase = lds0 + (uint32_t)(NSA * G::ASZ + sb * G::BSZ) + brow * 128u;
+        const uint32_t zrow = lds0 + (uint32_t)G::ZOFF;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const uint32_t kc = (uint32_t)(fq + 4 * (h * KS + u));
+            lds_cptr ap = (lds_cptr)(size_t)(abase + ((kc ^ (uint32_t)(fr & 7)) << 4));
+            lds_cptr bp = (lds_cptr)(size_t)(bbase + ((kc ^ (brow & 7u)) << 4));
+#pragma unroll
+            for (int i = 0; i < CBW; ++i) a[u][i] = *reinterpret_cast<lds_fptr>(ap + i * 2048);
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) {
+                lds_cptr bj = bp;
+                if constexpr (Q != 1) {
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)(Q == 0 ? hm0 : hm2), j, 1);   // all ones: horizontally padded tap
+                    bj = (lds_cptr)(size_t)((t & (zrow - (uint32_t)(j * 2048))) | (~t & (uint32_t)(size_t)bp));
+                }
+                b[u][j] = *reinterpret_cast<lds_fptr>(bj + j * 2048);
+            }
+        }
+    };
+    auto mfmas = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int u = 0; u < KS; ++u)
+#pragma unroll
+            for (int j = 0; j < PBW; ++j)
+#pragma unroll
+                for (int i = 0; i < CBW; ++i) acc[i][j] = Mma<DT>::run(a[u][i], b[u][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // every fragment read of this wave has returned (a compiler-visible wait: lgkmcnt(0), the other counters untouched)
+    auto reads_done = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xC07F); };
+
+    // Epilogue: v = acc * scale + shift -> act -> (+ residual) -> post_act -> one 16-byte NHWC store per (channel pair, pixel
+    // block). Branch-free: pad channels / rows past the tile read clamped table entries and an out-of-range (zero) residual and
+    // are dropped by the store's range check. Activations: none / ReLU / ReLU6 only (the host sends anything else to the generic
+    // kernel) - one inlined copy of this code per wave group.
+    // Packed weight row (16 i + rho) of a 64-row group holds channel 32 (i >> 1) + 8 (rho >> 2) + 4 (i & 1) + (rho & 3): lane group
+    // fq owns the 8 consecutive channels 32 ip + 8 fq .. + 7 of a pixel (accumulators 2 ip and 2 ip + 1).
+    const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        const int chTile = t % p.nChTiles;
+        const int tileP0 = (t / p.nChTiles) * BP;
+        const int mBase = tileP0 + wp * 16 * PBW + fr;
+#pragma unroll
+        for (int ip = 0; ip < CBW / 2; ++ip) {
+            const int ch0 = chTile * BM + wc * 16 * CBW + 32 * ip + 8 * fq;
+            const bool chok = ch0 < p.Cout;
+            const int chl = chok ? ch0 : 0;                      // table index of a pad channel: any valid one (never stored)
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + chl), s1 = *reinterpret_cast<const f32x4*>(p.scale + chl + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.shift + chl), h1 = *reinterpret_cast<const f32x4*>(p.shift + chl + 4);
+            u32x4 rr[PBW];
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) {
+                const int m = mBase + 16 * j;
+                const uint32_t roff = (chok && m < p.M) ? (uint32_t)(((size_t)m * p.Cout + ch0) * 2) : 0x80000000u;
+                rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);        // no residual: zero records -> zeros
+            }
+#pragma unroll
+            for (int j = 0; j < PBW; ++j) {
+                const int m = mBase + 16 * j;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * ip][j][e] * s0[e] + h0[e];
+                    v[4 + e] = acc[2 * ip + 1][j][e] * s1[e] + h1[e];
+                }
+                clampn<8>(v, act);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo, hi;
+                    unpack2<DT>(rr[j][e], lo, hi);
+                    v[2 * e] += lo;
+                    v[2 * e + 1] += hi;
+                }
+                clampn<8>(v, pact);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                const bool ok = chok && m < p.M;
+                const uint32_t boff = ok ? (uint32_t)(((size_t)m * p.Ypitch + ch0) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
+            }
+        }
+    };
+
+    auto sync = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: weight tiles of K-steps 0 and 1, activation tile of group 0, the zero row -----------------------------------
+    zero_acc();
+    setup_a(tile0);
+    setup_b(tile0);
+    setup_masks(tile0);
+    if (wave == 0 && lane < 8) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + lane * 16)) = (u32x4){0u, 0u, 0u, 0u};
+    dma_b(C0{}, CBN{});
+    advance_b();
+    dma_a(C0{}, CAN{});
+    advance_a();
+    if (K_total > 1) {
+        dma_a(C0{}, CAN{});
+        advance_a();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    sync();
+
+    int sa = 0, sb = 0, k = 0, cur_tile = tile0, ep_tile = tile0;
+    bool ep = false;
+#ifdef D3X3_STAMPS
+    int stamps = 0;
+#endif
+    // One K-step (filter column Q of the current group). `s` = global K-step index of this block.
+    //   interval 0: group 0 reads (first section) and issues this K-step's DMA | group 1 finishes K-step s - 1 (+ epilogue)
+    //   interval 1: group 0 computes | group 1 reads and issues its DMA;  KS == 1: two more intervals for the second K-half
+    // Returns true after the tail (s == K_total: group 1's last section and both groups' last epilogue).
+    auto kstep = [&](int s, auto Qc) __attribute__((always_inline)) -> bool {
+        constexpr int Q = decltype(Qc)::value;
+        constexpr int NBQ = Q == 0 ? G::NB0 : (Q == 1 ? G::NB1 : 0);
+        if constexpr (GRP == 1) {
+            if (s > 0) mfmas();
+        }
+        if constexpr (Q == 0) {                               // a tile ends behind q = 2 (nk is a multiple of 3)
+            if (ep) {
+                epilogue(ep_tile);
+                zero_acc();
+                if (s < K_total) setup_masks(cur_tile);
+            }
+            if (s == K_total) return true;
+        }
+        const bool moreA = la_g < K_total, moreB = lb_g < G_total;      // K-step s + 2 / group g + 1 exist
+        // DMA goes out BEHIND the section's fragment reads, once they have returned: a piece issued while the LDS is busy with
+        // the group's ds_reads costs its wave ~100 cycles (stamps), in the idle tail of the section a fraction of that - and
+        // that tail is time the wave would spend at the barrier anyway, waiting for the other group's MFMAs.
+        auto issue0 = [&]() __attribute__((always_inline)) {
+            if constexpr (Q == 0) { if (moreB) dma_b(C0{}, CB0{}); }
+            if constexpr (Q == 1) { if (moreB) { dma_b(CB0{}, CBN{}); advance_b(); } }
+            if (moreA) {
+                dma_a(C0{}, CA0{});
+                if constexpr (KS == 2) advance_a();
+            }
+        };
+        auto issue1 = [&]() __attribute__((always_inline)) {
+            if (moreA) {
+                dma_a(CA0{}, CAN{});
+                advance_a();
+            }
+        };
+        if constexpr (GRP == 0) {
+            reads(sa, sb, Qc, 0);
+            reads_done();
+            issue0();
+        }
+        D3_STAMP(0);
+        sync();
+        D3_STAMP(1);
+        if constexpr (GRP == 0) {
+            mfmas();
+        } else {
+            reads(sa, sb, Qc, 0);
+            reads_done();
+            issue0();
+        }
+        if constexpr (KS == 1) {
+            D3_STAMP(2);
+            sync();
+            D3_STAMP(3);
+            if constexpr (GRP == 0) {
+                reads(sa, sb, Qc, 1);
+                reads_done();
+                issue1();
+            } else {
+                mfmas();
+            }
+            D3_STAMP(4);
+            sync();
+            D3_STAMP(5);
+            if constexpr (GRP == 0) {
+                mfmas();
+            } else {
+                reads(sa, sb, Qc, 1);
+                reads_done();
+                issue1();
+            }
+        }
+        ep = (k == nk - 1);
+        ep_tile = cur_tile;
+        if (++k == nk) {
+            k = 0;
+            cur_tile += tstride;
+        }
+        sa = sa + 1 == NSA ? 0 : sa + 1;
+        if constexpr (Q == 2) sb ^= 1;
+        D3_STAMP(6);
+        // everything this wave issued BEFORE this K-step has landed: the weight tile of K-step s + 1 and, behind q = 2, the
+        // activation tile of the next group (its pieces went out during q = 0 and q = 1). What went out during this K-step
+        // (WLW weight pieces, NBQ activation pieces) may stay in flight.
+        if (moreA && (NBQ == 0 || moreB)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW + NBQ) : "memory");
+        else if (moreA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        D3_STAMP(7);
+        sync();
+        D3_STAMP(8);
+        return false;
+    };
+    for (int s = 0;; s += 3) {
+        if (kstep(s, std::integral_constant<int, 0>{})) break;
+        if (kstep(s + 1, std::integral_constant<int, 1>{})) break;
+        if (kstep(s + 2, std::integral_constant<int, 2>{})) break;
+    }
+#ifdef D3X3_STAMPS
+    if (p.dbg != nullptr && blockIdx.x == 16) p.dbg[wave * 64 + lane] = (uint32_t)stamps;
+#endif
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
+template <int DT, int WC, int WP, int CBW, int PBW, int KS>
+__global__ __launch_bounds__(512, 2) void d3q_kernel(const D3Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically): one wave of each group per SIMD
+    if (wave < 4) d3q_body<DT, WC, WP, CBW, PBW, KS, 0>(p, smem, wave);
+    else d3q_body<DT, WC, WP, CBW, PBW, KS, 1>(p, smem, wave);
+#endif  // __HIP_DEVICE_COMPILE__
+}

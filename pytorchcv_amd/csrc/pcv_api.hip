@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
-#include "d3x3_inst.hpp"
+#include "d3q_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
@@ -22,8 +22,8 @@
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
 IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
-D3X3_SHAPES(D3X3_DECLARE, PCV_BF16)
-D3X3_SHAPES(D3X3_DECLARE, PCV_F16)
+D3Q_SHAPES(D3Q_DECLARE, PCV_BF16)
+D3Q_SHAPES(D3Q_DECLARE, PCV_F16)
 
 struct pcv_ctx {
     int device = 0;
@@ -341,15 +341,15 @@ static int enable_gconv(pcv_ctx* ctx) {
         }
     return PCV_OK;
 }
-// ---- 8-wave dense 3x3 kernel (d3x3_conv.hpp) ----------------------------------------------------------------------------
+// ---- 8-wave dense 3x3 kernel (d3q_conv.hpp) -----------------------------------------------------------------------------
 struct D3Shape { int BM, BP, lds; const void* fn[2]; };       // fn[0] bf16, fn[1] fp16
-#define D3X3_ROW(DT, WC, WP, CBW, PBW, KS)                                                                   \
+#define D3Q_ROW(DT, WC, WP, CBW, PBW, KS)                                                                    \
     {D3Cfg<WC, WP, CBW, PBW, KS>::BM, D3Cfg<WC, WP, CBW, PBW, KS>::BP, D3Cfg<WC, WP, CBW, PBW, KS>::LDS,     \
-     {reinterpret_cast<const void*>(d3x3_kernel<PCV_BF16, WC, WP, CBW, PBW, KS>),                            \
-      reinterpret_cast<const void*>(d3x3_kernel<PCV_F16, WC, WP, CBW, PBW, KS>)}},
-static const D3Shape kD3[] = {D3X3_SHAPES(D3X3_ROW, 0)};
+     {reinterpret_cast<const void*>(d3q_kernel<PCV_BF16, WC, WP, CBW, PBW, KS>),                             \
+      reinterpret_cast<const void*>(d3q_kernel<PCV_F16, WC, WP, CBW, PBW, KS>)}},
+static const D3Shape kD3[] = {D3Q_SHAPES(D3Q_ROW, 0)};
 static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
-static const int kD3Auto = 9;                                 // shapes the cost model may pick (the rest are A/B variants)
+static const int kD3Auto = 7;                                 // shapes the cost model may pick (the rest are A/B variants)
 static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
@@ -891,7 +891,8 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     // ---- dense 3x3 / s1 / p1, 16 bit: the 8-wave kernel -----------------------------------------------------------------------
     int d3shape = -1;
     if (P.conv3 && !gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && d->act <= PCV_ACT_RELU6 && d->post_act <= PCV_ACT_RELU6 &&
-        scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull &&
+        xbytes + 2ull * (unsigned long long)d->W * d->Cin * 2ull < 0x80000000ull) {
         d3shape = ctx->use_d3x3 > 0 ? std::min(ctx->use_d3x3 - 1, kD3Count - 1)
                                     : pick_d3x3((long long)M64, d->Cout, P.nk, (long long)ctx->num_cu);
     }
