@@ -21,16 +21,21 @@
 //     in column 0 (q = 0) or W - 1 (q = 2) reads a zero row instead (address select, two VALU per fragment; q = 1 none).
 //     DMA bytes per K-step: 256 x 208 tile 58 -> 41 KB, 128 x 416 68 -> 34 KB, 64 x 448 64 -> 27 KB.
 //   * The LDS this frees holds a 3-deep ring of weight tiles (A): the pieces of K-step k + 2 and of group g + 1 are issued
-//     during K-step k by every wave in the read section it has anyway, two K-steps ahead of their first use; `s_waitcnt
-//     vmcnt(N)` with N = the pieces issued during the current K-step, raw `s_barrier`, never a drain.
-//   * 512 threads, one block per CU; waves 0-3 and 4-7 (one of each per SIMD) run one barrier interval apart - while one
-//     group reads fragments, the other's MFMAs own the matrix pipe (MI355X_MICROARCH.md, "Two waves per SIMD"). KS K-halves
-//     per section: a K-step is 4 (KS = 1) or 2 (KS = 2) barrier intervals.
+//     during K-step k, two K-steps ahead of their first use; `s_waitcnt vmcnt(N)` with N = the pieces issued during the
+//     current K-step, raw `s_barrier`, never a drain.
+//   * 768 threads, one block per CU: EIGHT COMPUTE waves + FOUR LOADER waves (three waves per SIMD, 168 registers each).
+//     Stamps of the self-loading variants put one LDS-DMA piece at ~100 cycles of its issuing wave whatever the placement
+//     (in front of the MFMAs, beside the fragment reads, behind them): 6 pieces per wave and K-step stretched every interval
+//     that carried them from ~520 to ~1 020 cycles. A loader wave pays that price in cycles nobody else needs - its VMEM issue
+//     runs beside the compute waves' MFMA and LDS issue - and the compute waves' loop has no VMEM instruction left in it.
+//     Compute waves 0-3 and 4-7 (one of each per SIMD) run one barrier interval apart - while one group reads fragments, the
+//     other's MFMAs own the matrix pipe (MI355X_MICROARCH.md, "Two waves per SIMD"). KS K-halves per section: a K-step is
+//     4 (KS = 1) or 2 (KS = 2) barrier intervals; the loaders take part in every barrier.
 //   * Tile shapes chosen by the host so that the tile count fills whole rounds of the CUs (wave tiles of 7 or 13 pixel
 //     blocks: 112 / 208 / 416 / 448-pixel tiles).
 //
 // Barrier/visibility rules (cdna_hip_programming.md, "Read a staged buffer one phase AFTER the wait that retires it"):
-//   RAW  a wave waits for ITS pieces of K-step k + 1 / group g + 1 (counted vmcnt) before the barrier that ends K-step k;
+//   RAW  a loader waits for ITS pieces of K-step k + 1 / group g + 1 (counted vmcnt) before the barrier that ends K-step k;
 //        their first read is issued after that barrier.
 //   WAR  every fragment read is retired (lgkmcnt(0)) before the barrier that ends its interval; the A slot of K-step k - 1
 //        and the B slot of group g - 1 are re-filled from K-step k / 3 g on, after both groups' last reads of them.
@@ -86,64 +91,69 @@ struct D3Params {
 #define D3_STAMP(slot) do { } while (0)
 #endif
 
-// WC x WP: wave grid (channels x pixels), 8 waves. CBW / PBW: 16-row blocks per wave (channels / pixels).
+// WC x WP: compute-wave grid (channels x pixels), 8 waves. CBW / PBW: 16-row blocks per wave (channels / pixels).
 // KS: K-halves (32 elements each) per read / MFMA section.
 template <int WC, int WP, int CBW, int PBW, int KS> struct D3Cfg {
+    static constexpr int NLOAD = 4;                          // loader waves (waves 8..11)
+    static constexpr int THREADS = 64 * (8 + NLOAD);
     static constexpr int BM = 16 * CBW * WC;                 // channel rows per block tile
     static constexpr int BP = 16 * PBW * WP;                 // pixel rows per block tile
     static constexpr int NPA = BM / 8;                       // 1 KB DMA pieces (8 rows x 128 B) of one weight tile
-    static constexpr int WLW = NPA / 8;                      // ... per wave (every wave loads)
+    static constexpr int WLW = NPA / NLOAD;                  // ... per loader
     static constexpr int BROWS = (BP + 2 + 7) / 8 * 8;       // rows of one activation tile: flat pixels P0 - 1 .. P0 + BP, padded
     static constexpr int NPB = BROWS / 8;
-    static constexpr int XLW = (NPB + 7) / 8;                // activation pieces per wave per group (pieces past the tile: zeros into pad rows)
+    static constexpr int XLW = (NPB + NLOAD - 1) / NLOAD;    // activation pieces per loader per group
     static constexpr int NB0 = (XLW + 1) / 2, NB1 = XLW / 2; // ... issued during the group's K-steps q = 0 and q = 1
     static constexpr int ASZ = BM * 128;                     // bytes of one A slot
     static constexpr int BSZ = NPB * 1024;                   // bytes of one B slot
     static constexpr int NSA = 3;
     static constexpr int ZOFF = NSA * ASZ + 2 * BSZ;         // 128 zero bytes: the row a horizontally padded tap reads
-    static constexpr int DUMP = ZOFF + 128;                  // 1 KB: where the (8 XLW - NPB) surplus pieces of a group land (every wave
-                                                             // issues the same number of pieces so that the vmcnt counts are constants)
+    static constexpr int DUMP = ZOFF + 128;                  // 1 KB: where the (NLOAD XLW - NPB) surplus pieces of a group land (every
+                                                             // loader issues the same number of pieces: the vmcnt counts are constants)
     static constexpr int LDS = DUMP + 1024;
-    static_assert(WC * WP == 8, "eight waves");
+    static_assert(WC * WP == 8, "eight compute waves");
     static_assert(KS == 1 || KS == 2, "one or two K-halves per section");
-    static_assert(NPA % 8 == 0 && CBW % 2 == 0, "weight pieces split evenly over the waves; channel pairs per wave");
+    static_assert(NPA % NLOAD == 0 && CBW % 2 == 0, "weight pieces split evenly over the loaders; channel pairs per wave");
     static_assert(LDS <= 160 * 1024, "three weight tiles + two activation tiles must fit the LDS");
-    static_assert(XLW <= 10, "row masks of the activation pieces are packed 3 bits each into one register");
+    static_assert(XLW <= 20, "row masks of the activation pieces are packed 3 bits each, ten per register, two registers");
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// The whole persistent loop of one wave group (GRP 0: waves 0-3, GRP 1: waves 4-7, one barrier interval behind). The two
-// instantiations are separate straight-line loop nests (no per-interval group branches for the register allocator to join).
-template <int DT, int WC, int WP, int CBW, int PBW, int KS, int GRP>
-__device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const int wave) {
-    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
-    constexpr int BM = G::BM, BP = G::BP, WLW = G::WLW, XLW = G::XLW, NSA = G::NSA;
-    typedef typename Mma<DT>::frag frag;
-    typedef __attribute__((address_space(3))) char lds_char;
-
-    const int lane = threadIdx.x & 63;
-    const int wc = wave / WP, wp = wave % WP;
-    const int lrow = lane >> 3;
-    const int cs = (lane & 7) ^ lrow;                         // K-chunk this lane fetches (source-side swizzle)
-    const int fr = lane & 15, fq = lane >> 4;
-    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)PCV_LDS(smem));
-
-    // ---- this block's tiles: [tile0, tend) of its XCD's contiguous range, stride = blocks per XCD -------------------------
+// The tile list of a block: [tile0, tend) of its XCD's contiguous range, stride = blocks per XCD (every wave computes the same).
+struct D3Tiles {
+    int tile0, tend, tstride, nMine;
+};
+__device__ __forceinline__ D3Tiles d3q_tiles(const D3Params& p) {
+    D3Tiles t;
     const int perXcd = (p.nTiles + 7) >> 3;
     const int xcd = blockIdx.x & 7;
-    const int tstride = gridDim.x >> 3;                       // host guarantees gridDim.x % 8 == 0
-    const int tile0 = xcd * perXcd + (int)(blockIdx.x >> 3);
-    const int tend = min(p.nTiles, (xcd + 1) * perXcd);
-    if (tile0 >= tend) return;                                 // (whole block: the tile range does not depend on the wave)
-    const int nMine = (tend - tile0 + tstride - 1) / tstride;
-    const int nk = p.nk;
-    const int ngrp = nk / 3;                                   // groups (r, c) per tile
-    const int K_total = nMine * nk;                           // K-steps this block walks
-    const int G_total = nMine * ngrp;                         // groups
+    t.tstride = gridDim.x >> 3;                               // host guarantees gridDim.x % 8 == 0
+    t.tile0 = xcd * perXcd + (int)(blockIdx.x >> 3);
+    t.tend = min(p.nTiles, (xcd + 1) * perXcd);
+    t.nMine = t.tile0 < t.tend ? (t.tend - t.tile0 + t.tstride - 1) / t.tstride : 0;
+    return t;
+}
+__device__ __forceinline__ void d3q_sync() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
 
-    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res != nullptr ? p.res_bytes : 0u, 0x00020000);
+// ---- loader wave lw (0..3): every LDS-DMA piece of the block ------------------------------------------------------------------------
+template <int DT, int WC, int WP, int CBW, int PBW, int KS>
+__device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const int lw) {
+    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
+    constexpr int BM = G::BM, BP = G::BP, WLW = G::WLW, XLW = G::XLW, NSA = G::NSA, NL = G::NLOAD;
+    typedef __attribute__((address_space(3))) char lds_char;
+    const int lane = threadIdx.x & 63;
+    const int lrow = lane >> 3;
+    const int cs = (lane & 7) ^ lrow;                         // K-chunk this lane fetches (source-side swizzle)
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)PCV_LDS(smem));
+    const D3Tiles T = d3q_tiles(p);
+    if (T.nMine == 0) return;
+    const int nk = p.nk;
+    const int K_total = T.nMine * nk, G_total = T.nMine * (nk / 3);
+
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     // Activations: the descriptor's base sits one image row BELOW x, so that the (wave-uniform, unsigned) scalar offset of a
     // group, (r * W * Cin + 64 c) elements, reaches the row above a pixel with r = 0. num_records covers the per-lane offset
@@ -154,21 +164,19 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) - rowBytes, 0, p.x_bytes + 2u * rowBytes, 0x00020000);
 
-    // ---- DMA side ----------------------------------------------------------------------------------------------------------------
-    // weights: K-step `la_k` of tile `la_tile` goes to A slot la_slot; wave w owns pieces 8 i + w (rows 8 (8 i + w) + lrow)
-    int la_tile = tile0, la_k = 0, la_slot = 0, la_g = 0;      // la_g: global index of the next K-step to issue
+    // weights: K-step `la_k` of tile `la_tile` goes to A slot la_slot; loader lw owns pieces NL i + lw (rows 8 (NL i + lw) + lrow)
+    int la_tile = T.tile0, la_k = 0, la_slot = 0, la_g = 0;    // la_g: global index of the next K-step to issue
     uint32_t woff0 = 0;
     auto setup_a = [&](int t) __attribute__((always_inline)) {
         const int chTile = t % p.nChTiles;
-        woff0 = (uint32_t)(((chTile * BM + 8 * wave + lrow) * p.Kpad + cs * 8) * 2);     // rows past the blob: out of range -> zeros
+        woff0 = (uint32_t)(((chTile * BM + 8 * lw + lrow) * p.Kpad + cs * 8) * 2);       // rows past the blob: out of range -> zeros
     };
-    const uint32_t wstep = (uint32_t)(64 * p.Kpad * 2);        // 8 pieces x 8 rows further down the blob
-    // pieces [I0, I1) of the weight tile; `advance_a` steps to the next K-step once all WLW are out
-    auto dma_a = [&](auto I0c, auto I1c) __attribute__((always_inline)) {
+    const uint32_t wstep = (uint32_t)(8 * NL * p.Kpad * 2);    // NL pieces x 8 rows further down the blob
+    auto dma_a = [&](auto I0c, auto I1c) __attribute__((always_inline)) {                // pieces [I0, I1) of the weight tile
         constexpr int I0 = decltype(I0c)::value, I1 = decltype(I1c)::value;
 #pragma unroll
         for (int i = I0; i < I1; ++i) {
-            const uint32_t dst = lds0 + (uint32_t)(la_slot * G::ASZ + (8 * i + wave) * 1024);
+            const uint32_t dst = lds0 + (uint32_t)(la_slot * G::ASZ + (NL * i + lw) * 1024);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_char*)(size_t)dst, 16, woff0 + i * wstep, la_k * 128, 0, 0);
         }
     };
@@ -177,21 +185,21 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         la_slot = la_slot + 1 == NSA ? 0 : la_slot + 1;
         if (++la_k == nk) {
             la_k = 0;
-            la_tile += tstride;
-            if (la_tile < tend) setup_a(la_tile);
+            la_tile += T.tstride;
+            if (la_tile < T.tend) setup_a(la_tile);
         }
     };
-    // activations: group (lb_r, lb_c) of tile `lb_tile` goes to B slot lb_slot; wave w owns pieces 8 j + w: LDS rows
-    // u = 8 (8 j + w) + lrow <-> flat pixel P0 + u - 1, input pixel = that pixel shifted by (lb_r - 1) image rows
-    int lb_tile = tile0, lb_r = 0, lb_c = 0, lb_slot = 0, lb_g = 0;
-    uint32_t pbv[XLW];             // byte offset of the pixel itself (+ this lane's chunk), or 0x80000000 for a row outside [0, M) / the tile
-    uint32_t vmask = 0;            // 3 bits per piece: image row ho + r - 1 exists, r = 0, 1, 2
+    // activations: group (lb_r, lb_c) of tile `lb_tile` goes to B slot lb_slot; loader lw owns pieces NL j + lw: LDS rows
+    // u = 8 (NL j + lw) + lrow <-> flat pixel P0 + u - 1, input pixel = that pixel shifted by (lb_r - 1) image rows
+    int lb_tile = T.tile0, lb_r = 0, lb_c = 0, lb_slot = 0, lb_g = 0;
+    uint32_t pbv[XLW];             // byte offset of the pixel itself (+ this lane's chunk), or 2^31 for a row outside [0, M) / the tile
+    uint32_t vmask[2] = {0u, 0u};  // 3 bits per piece (ten per register): image row ho + r - 1 exists, r = 0, 1, 2
     auto setup_b = [&](int t) __attribute__((always_inline)) {
         const int tileP0 = (t / p.nChTiles) * BP;
-        vmask = 0;
+        vmask[0] = vmask[1] = 0u;
 #pragma unroll
         for (int j = 0; j < XLW; ++j) {
-            const int u = 8 * (8 * j + wave) + lrow;
+            const int u = 8 * (NL * j + lw) + lrow;
             const int m = tileP0 + u - 1;
             uint32_t off = 0x80000000u, vm = 0;
             if (u < BP + 2 && m >= 0 && m < p.M) {
@@ -201,18 +209,17 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 vm = (ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u);
             }
             pbv[j] = off;
-            vmask |= vm << (3 * j);
+            vmask[j / 10] |= vm << (3 * (j % 10));
         }
     };
-    // pieces [J0, J1) of the group
-    auto dma_b = [&](auto J0c, auto J1c) __attribute__((always_inline)) {
+    auto dma_b = [&](auto J0c, auto J1c) __attribute__((always_inline)) {                // pieces [J0, J1) of the group
         constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
         const uint32_t soff = (uint32_t)(lb_r * p.W * p.Cin + lb_c * 64) * 2u;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
-            const uint32_t dst = lds0 + (uint32_t)(8 * j + wave < G::NPB ? NSA * G::ASZ + lb_slot * G::BSZ + (8 * j + wave) * 1024 : G::DUMP);
-            const int t = __builtin_amdgcn_sbfe((int)vmask, 3 * j + lb_r, 1);                  // -1: the image row exists
-            const uint32_t voff = ((uint32_t)t & pbv[j]) | (~(uint32_t)t & 0x80000000u);
+            const uint32_t dst = lds0 + (uint32_t)(NL * j + lw < G::NPB ? NSA * G::ASZ + lb_slot * G::BSZ + (NL * j + lw) * 1024 : G::DUMP);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)vmask[j / 10], 3 * (j % 10) + lb_r, 1);    // all ones: the image row exists
+            const uint32_t voff = (t & pbv[j]) | (~t & 0x80000000u);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_char*)(size_t)dst, 16, voff, soff, 0, 0);
         }
     };
@@ -223,20 +230,84 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
             lb_c = 0;
             if (++lb_r == 3) {
                 lb_r = 0;
-                lb_tile += tstride;
-                if (lb_tile < tend) setup_b(lb_tile);
+                lb_tile += T.tstride;
+                if (lb_tile < T.tend) setup_b(lb_tile);
             }
         }
     };
     typedef std::integral_constant<int, 0> C0;
     typedef std::integral_constant<int, G::NB0> CB0;
     typedef std::integral_constant<int, XLW> CBN;
-    // weight pieces issued behind the first / second read section of a K-step (KS == 2 has one section)
-    constexpr int WA0 = KS == 2 ? WLW : (WLW + 1) / 2;
+    constexpr int WA0 = (WLW + 1) / 2;                          // weight pieces issued in the first half of a K-step
     typedef std::integral_constant<int, WA0> CA0;
     typedef std::integral_constant<int, WLW> CAN;
 
-    // ---- compute side -------------------------------------------------------------------------------------------------------
+    // prologue: weight tiles of K-steps 0 and 1, activation tile of group 0, the zero row
+    setup_a(T.tile0);
+    setup_b(T.tile0);
+    if (lw == 0 && lane < 8) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + lane * 16)) = (u32x4){0u, 0u, 0u, 0u};
+    dma_b(C0{}, CBN{});
+    advance_b();
+    dma_a(C0{}, CAN{});
+    advance_a();
+    if (K_total > 1) {
+        dma_a(C0{}, CAN{});
+        advance_a();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    d3q_sync();
+
+    // One K-step: the pieces of K-step s + 2 (weights) and, during q = 0 and q = 1, of the next group (activations), spread
+    // over the K-step's barrier intervals; before its last barrier everything issued BEFORE this K-step has landed - the
+    // weight tile of K-step s + 1 and, behind q = 2, the activation tile of the next group.
+    auto kstep = [&](auto Qc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(Qc)::value;
+        constexpr int NBQ = Q == 0 ? G::NB0 : (Q == 1 ? G::NB1 : 0);
+        const bool moreA = la_g < K_total, moreB = lb_g < G_total;      // K-step s + 2 / group g + 1 exist
+        if constexpr (Q == 0) { if (moreB) dma_b(C0{}, CB0{}); }
+        if constexpr (Q == 1) { if (moreB) { dma_b(CB0{}, CBN{}); advance_b(); } }
+        if (moreA) dma_a(C0{}, CA0{});
+        d3q_sync();
+        if constexpr (KS == 1) d3q_sync();
+        if (moreA) {
+            dma_a(CA0{}, CAN{});
+            advance_a();
+        }
+        if constexpr (KS == 1) d3q_sync();
+        if (moreA && (NBQ == 0 || moreB)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW + NBQ) : "memory");
+        else if (moreA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        d3q_sync();
+    };
+    for (int s = 0; s < K_total; s += 3) {
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+    }
+}
+
+// ---- compute waves: the whole persistent loop of one group (GRP 0: waves 0-3, GRP 1: waves 4-7, one barrier interval behind). ------
+// The two instantiations are separate straight-line loop nests (no per-interval group branches for the register allocator to join).
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, int GRP>
+__device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const int wave) {
+    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
+    constexpr int BM = G::BM, BP = G::BP, NSA = G::NSA;
+    typedef typename Mma<DT>::frag frag;
+
+    const int lane = threadIdx.x & 63;
+    const int wc = wave / WP, wp = wave % WP;
+    const int fr = lane & 15, fq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)PCV_LDS(smem));
+    const D3Tiles T = d3q_tiles(p);
+    if (T.nMine == 0) return;
+    const int nk = p.nk;
+    const int K_total = T.nMine * nk;                         // K-steps this block walks
+
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res != nullptr ? p.res_bytes : 0u, 0x00020000);
+
     f32x4 acc[CBW][PBW];
     frag a[KS][CBW], b[KS][PBW];
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -355,42 +426,21 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         }
     };
 
-    auto sync = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // ---- prologue: weight tiles of K-steps 0 and 1, activation tile of group 0, the zero row -----------------------------------
     zero_acc();
-    setup_a(tile0);
-    setup_b(tile0);
-    setup_masks(tile0);
-    if (wave == 0 && lane < 8) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + lane * 16)) = (u32x4){0u, 0u, 0u, 0u};
-    dma_b(C0{}, CBN{});
-    advance_b();
-    dma_a(C0{}, CAN{});
-    advance_a();
-    if (K_total > 1) {
-        dma_a(C0{}, CAN{});
-        advance_a();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    sync();
+    setup_masks(T.tile0);
+    d3q_sync();                                                // the loaders' prologue: K-steps 0 and 1, group 0, the zero row
 
-    int sa = 0, sb = 0, k = 0, cur_tile = tile0, ep_tile = tile0;
+    int sa = 0, sb = 0, k = 0, cur_tile = T.tile0, ep_tile = T.tile0;
     bool ep = false;
 #ifdef D3X3_STAMPS
     int stamps = 0;
 #endif
     // One K-step (filter column Q of the current group). `s` = global K-step index of this block.
-    //   interval 0: group 0 reads (first section) and issues this K-step's DMA | group 1 finishes K-step s - 1 (+ epilogue)
-    //   interval 1: group 0 computes | group 1 reads and issues its DMA;  KS == 1: two more intervals for the second K-half
+    //   interval 0: group 0 reads (first section) | group 1 finishes K-step s - 1 (+ epilogue)
+    //   interval 1: group 0 computes | group 1 reads;  KS == 1: two more intervals for the second K-half
     // Returns true after the tail (s == K_total: group 1's last section and both groups' last epilogue).
     auto kstep = [&](int s, auto Qc) __attribute__((always_inline)) -> bool {
         constexpr int Q = decltype(Qc)::value;
-        constexpr int NBQ = Q == 0 ? G::NB0 : (Q == 1 ? G::NB1 : 0);
         if constexpr (GRP == 1) {
             if (s > 0) mfmas();
         }
@@ -402,78 +452,49 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
             }
             if (s == K_total) return true;
         }
-        const bool moreA = la_g < K_total, moreB = lb_g < G_total;      // K-step s + 2 / group g + 1 exist
-        // DMA goes out BEHIND the section's fragment reads, once they have returned: a piece issued while the LDS is busy with
-        // the group's ds_reads costs its wave ~100 cycles (stamps), in the idle tail of the section a fraction of that - and
-        // that tail is time the wave would spend at the barrier anyway, waiting for the other group's MFMAs.
-        auto issue0 = [&]() __attribute__((always_inline)) {
-            if constexpr (Q == 0) { if (moreB) dma_b(C0{}, CB0{}); }
-            if constexpr (Q == 1) { if (moreB) { dma_b(CB0{}, CBN{}); advance_b(); } }
-            if (moreA) {
-                dma_a(C0{}, CA0{});
-                if constexpr (KS == 2) advance_a();
-            }
-        };
-        auto issue1 = [&]() __attribute__((always_inline)) {
-            if (moreA) {
-                dma_a(CA0{}, CAN{});
-                advance_a();
-            }
-        };
         if constexpr (GRP == 0) {
             reads(sa, sb, Qc, 0);
             reads_done();
-            issue0();
         }
         D3_STAMP(0);
-        sync();
+        d3q_sync();
         D3_STAMP(1);
         if constexpr (GRP == 0) {
             mfmas();
         } else {
             reads(sa, sb, Qc, 0);
             reads_done();
-            issue0();
         }
         if constexpr (KS == 1) {
             D3_STAMP(2);
-            sync();
+            d3q_sync();
             D3_STAMP(3);
             if constexpr (GRP == 0) {
                 reads(sa, sb, Qc, 1);
                 reads_done();
-                issue1();
             } else {
                 mfmas();
             }
             D3_STAMP(4);
-            sync();
+            d3q_sync();
             D3_STAMP(5);
             if constexpr (GRP == 0) {
                 mfmas();
             } else {
                 reads(sa, sb, Qc, 1);
                 reads_done();
-                issue1();
             }
         }
         ep = (k == nk - 1);
         ep_tile = cur_tile;
         if (++k == nk) {
             k = 0;
-            cur_tile += tstride;
+            cur_tile += T.tstride;
         }
         sa = sa + 1 == NSA ? 0 : sa + 1;
         if constexpr (Q == 2) sb ^= 1;
-        D3_STAMP(6);
-        // everything this wave issued BEFORE this K-step has landed: the weight tile of K-step s + 1 and, behind q = 2, the
-        // activation tile of the next group (its pieces went out during q = 0 and q = 1). What went out during this K-step
-        // (WLW weight pieces, NBQ activation pieces) may stay in flight.
-        if (moreA && (NBQ == 0 || moreB)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW + NBQ) : "memory");
-        else if (moreA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         D3_STAMP(7);
-        sync();
+        d3q_sync();
         D3_STAMP(8);
         return false;
     };
@@ -489,12 +510,13 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
 #endif  // __HIP_DEVICE_COMPILE__
 
 template <int DT, int WC, int WP, int CBW, int PBW, int KS>
-__global__ __launch_bounds__(512, 2) void d3q_kernel(const D3Params p) {
+__global__ __launch_bounds__(768, 3) void d3q_kernel(const D3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically): one wave of each group per SIMD
+    // compute waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically), loader w + 8 joins them
     if (wave < 4) d3q_body<DT, WC, WP, CBW, PBW, KS, 0>(p, smem, wave);
-    else d3q_body<DT, WC, WP, CBW, PBW, KS, 1>(p, smem, wave);
+    else if (wave < 8) d3q_body<DT, WC, WP, CBW, PBW, KS, 1>(p, smem, wave);
+    else d3q_loader<DT, WC, WP, CBW, PBW, KS>(p, smem, wave - 8);
 #endif  // __HIP_DEVICE_COMPILE__
 }

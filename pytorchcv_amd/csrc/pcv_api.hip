@@ -349,33 +349,25 @@ struct D3Shape { int BM, BP, lds; const void* fn[2]; };       // fn[0] bf16, fn[
       reinterpret_cast<const void*>(d3q_kernel<PCV_F16, WC, WP, CBW, PBW, KS>)}},
 static const D3Shape kD3[] = {D3Q_SHAPES(D3Q_ROW, 0)};
 static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
-static const int kD3Auto = 7;                                 // shapes the cost model may pick (the rest are A/B variants)
 static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
     return PCV_OK;
 }
-// Tile shape for M pixels x Cout channels on `slots` CUs (one block each): rounds of the tile schedule x cycles per tile. A K-step
-// costs its MFMA time (at the ~85 % issue efficiency of a section) PLUS its LDS-DMA time - in-kernel stamps show the two
-// serialised: the L2 -> LDS path delivers ~37 B/clk/CU and the issuing waves block on it - plus four barrier intervals.
-// Returns -1 where the generic 4-wave kernel is the better choice: 64-channel layers (two thirds of a K-step's bytes are
-// re-fetched activation rows: 106 vs 95 us on ResNet-50's 56x56x64 layer) and launches that cannot fill a quarter of the CUs.
+// Tile shape for M pixels x Cout channels on `slots` CUs (one block each). With the activation tile staged once per filter row
+// the bytes a K-step pulls through L2 are BM x 128 (weights) + BP x 128 / 3 (activations): wide pixel tiles with no more channel
+// rows than needed. Measured on ResNet-50's four 3x3 layers (batch 256, us, generic -> this kernel): 64 ch 95 -> 85 (64 x 448),
+// 128 ch 80 -> 69 (128 x 224), 256 ch 78 -> 64 (128 x 224; 256 x 112: 65), 512 ch 78 -> 63. The 64-pixel-per-wave shapes take over
+// when the wide tile would leave more than half of the CUs without a tile; below a quarter of the CUs the generic 4-wave
+// kernel (two blocks per CU, 128 x 128 tiles) fills the chip better: -1.
 static int pick_d3x3(long long M, int Cout, int nk, long long slots) {
-    if (Cout <= 64) return -1;
-    int best = -1;
-    double best_cost = 0.0;
-    long long best_tiles = 0;
-    for (int i = 0; i < kD3Auto; ++i) {
-        const long long nCh = (Cout + kD3[i].BM - 1) / kD3[i].BM, nP = (M + kD3[i].BP - 1) / kD3[i].BP;
-        const long long rounds = (nCh * nP + slots - 1) / slots;
-        const double mfma = (double)kD3[i].BM * kD3[i].BP / 32.0 / 0.85, dmac = (double)(kD3[i].BM + kD3[i].BP) * 128.0 / 37.0;
-        const double tile = nk * (mfma + dmac + 520.0) + (double)kD3[i].BM * kD3[i].BP / 16.0;
-        const double cost = (double)rounds * tile;
-        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_tiles = nCh * nP; }
-    }
-    if (best_tiles * 4 < slots) return -1;
-    return best;
+    (void)nk;
+    const int wide = Cout <= 64 ? 2 : 1, narrow = Cout <= 64 ? 5 : 4;          // d3q_inst.hpp order
+    auto tiles = [&](int i) { return ((Cout + kD3[i].BM - 1) / kD3[i].BM) * ((M + kD3[i].BP - 1) / kD3[i].BP); };
+    if (tiles(wide) * 2 >= slots) return wide;
+    if (tiles(narrow) * 4 >= slots) return narrow;
+    return -1;
 }
 
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
@@ -925,7 +917,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         long long nb = slots < nT ? slots : nT;
         nb = (nb + 7) / 8 * 8;
         void* args[] = {&q};
-        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(512), args, (size_t)S.lds, (hipStream_t)stream));
+        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));
         return PCV_OK;
     }
 

@@ -133,7 +133,7 @@ _CONV3_SHAPES = [
 
 
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(9)])
+@pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(8)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
 def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device):

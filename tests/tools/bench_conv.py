@@ -13,7 +13,7 @@ LAYERS = [  # (N, Cin, Cout, H, k, stride, groups, residual)
     (256, 64, 64, 56, 3, 1, 1, False), (256, 128, 128, 28, 3, 1, 1, False), (256, 256, 256, 14, 3, 1, 1, False),
     (256, 512, 512, 7, 3, 1, 1, False),
 ]
-SHAPES = ["256x208", "256x224", "256x112", "128x416", "128x224", "64x448", "64x256", "256x224k1", "256x112k1"]     # d3q_inst.hpp order
+SHAPES = ["256x112", "128x224", "64x448", "256x64", "128x128", "64x256", "256x112k1", "64x448k1"]     # d3q_inst.hpp order
 VARIANTS = {"generic": {"d3x3": 0}, "auto": {"d3x3": -1}}
 VARIANTS.update({"d3:" + n: {"d3x3": i + 1} for i, n in enumerate(SHAPES)})
 if len(sys.argv) > 1:
