@@ -39,6 +39,24 @@ class Quant(object):
             return t
         return t.to(self.dtype).to(torch.float32)
 
+    # The individual rounding points (all `r` in the pipeline the GPU path runs). tests/tools/bf16_drift.py overrides them one
+    # at a time to attribute the distance between the 16-bit forward and the fp32 reference forward.
+    def rw(self, w: torch.Tensor) -> torch.Tensor:
+        """convolution weights as MFMA operands"""
+        return self.r(w)
+
+    def rc(self, w: torch.Tensor) -> torch.Tensor:
+        """classifier weights behind the global pool: the GPU path runs the head in fp32 (engine.FP32_HEAD)"""
+        return w
+
+    def ro(self, y: torch.Tensor, is_unit_output: bool = False) -> torch.Tensor:
+        """an activation tensor stored to HBM (`is_unit_output`: the residual stream, written by a unit's last convolution)"""
+        return self.r(y)
+
+    def rp(self, f: torch.Tensor) -> torch.Tensor:
+        """the pooled feature vector handed to the classifier, and activations inside the head: fp32 on the GPU path"""
+        return f
+
     @property
     def on(self) -> bool:
         return self.dtype is not None
@@ -91,7 +109,7 @@ def conv_block(sd: dict, prefix: str, x: torch.Tensor, stride=1, padding=0, dila
         x = F.pad(x, padding)
         padding = 0
     if q.on:
-        y = F.conv2d(x, q.r(w), None, stride, padding, dilation, groups)
+        y = F.conv2d(x, q.rw(w), None, stride, padding, dilation, groups)
         if normalize:
             scale, shift = fold_bn(sd, prefix + "bn.", eps)
             if bias is not None:
@@ -110,7 +128,7 @@ def conv_block(sd: dict, prefix: str, x: torch.Tensor, stride=1, padding=0, dila
     if residual is not None:
         y = y + residual
     y = _act(y, post_act)
-    return q.r(y)
+    return q.ro(y, residual is not None)
 
 
 def se_block(sd: dict, prefix: str, x: torch.Tensor, q: Quant | None = None,
@@ -172,9 +190,9 @@ def _res_init_block(sd, x, q):
 
 def _classifier(sd, x, q):
     # resnet.py:316-322,333-337: AvgPool2d(7, stride=1) -> view -> Linear
-    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
+    x = q.rp(F.avg_pool2d(x, kernel_size=7, stride=1))
     x = x.view(x.size(0), -1)
-    return F.linear(x, q.r(sd["output.weight"].float()), sd["output.bias"].float())
+    return F.linear(x, q.rc(sd["output.weight"].float()), sd["output.bias"].float())
 
 
 def _res_layers(blocks: int, bottleneck: bool | None):
@@ -352,9 +370,9 @@ def mobilenetv2_forward(sd, x, width_scale=1.0, q=None, taps=None):
             in_ch = out_ch
         _tap(taps, "stage{}".format(i + 1), x)
     x = conv_block(sd, "features.final_block.", x, act="relu6", q=q)
-    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
+    x = q.rp(F.avg_pool2d(x, kernel_size=7, stride=1))
     # mobilenetv2.py:138-141,154-155: bias-free 1x1 conv classifier, then view
-    x = F.conv2d(x, q.r(sd["output.weight"].float()))
+    x = F.conv2d(x, q.rc(sd["output.weight"].float()))
     return x.view(x.size(0), -1)
 
 
@@ -394,9 +412,9 @@ def mobilenetv3_forward(sd, x, version="large", q=None, taps=None):
     x = conv_block(sd, "features.final_block.conv.", x, act="hswish", q=q)
     if "features.final_block.se.conv1.weight" in sd:
         x = se_block(sd, "features.final_block.se.", x, q=q, out_act="hsigmoid")
-    x = q.r(F.avg_pool2d(x, kernel_size=7, stride=1))
-    x = q.r(_act(F.conv2d(x, q.r(sd["output.conv1.weight"].float())), "hswish"))
-    x = F.conv2d(x, q.r(sd["output.conv2.weight"].float()), sd["output.conv2.bias"].float())   # dropout: identity in eval
+    x = q.rp(F.avg_pool2d(x, kernel_size=7, stride=1))
+    x = q.rp(_act(F.conv2d(x, q.rc(sd["output.conv1.weight"].float())), "hswish"))
+    x = F.conv2d(x, q.rc(sd["output.conv2.weight"].float()), sd["output.conv2.bias"].float())   # dropout: identity in eval
     return x.view(x.size(0), -1)
 
 
@@ -666,9 +684,9 @@ def efficientnet_forward(sd, x, version="b0", tf_mode=False, bn_eps=1e-5, q=None
             j += 1
         _tap(taps, "stage{}".format(i + 1), x)
     x = conv_block(sd, "features.final_block.", x, act="swish", q=q, eps=bn_eps)
-    x = q.r(x.mean(dim=(2, 3), keepdim=True))                              # AdaptiveAvgPool2d(1), :339
+    x = q.rp(x.mean(dim=(2, 3), keepdim=True))                             # AdaptiveAvgPool2d(1), :339
     x = x.view(x.size(0), -1)
-    return F.linear(x, q.r(sd["output.fc.weight"].float()), sd["output.fc.bias"].float())   # dropout: identity in eval
+    return F.linear(x, q.rc(sd["output.fc.weight"].float()), sd["output.fc.bias"].float())   # dropout: identity in eval
 
 
 MODEL_ARCH = {

@@ -22,13 +22,15 @@ class MaxPool2dNHWC(nn.Module):
 
 
 class AvgPool2dNHWC(nn.Module):
-    """nn.AvgPool2d(kernel_size, stride) `final_pool` (reference resnet.py:316-318) -> pcv_avgpool2d."""
+    """nn.AvgPool2d(kernel_size, stride) `final_pool` (reference resnet.py:316-318) -> pcv_avgpool2d. As a net's `final_pool`
+    (the classifier input) it hands fp32 pooled features to the fp32 head (engine.FP32_HEAD)."""
     def __init__(self, kernel_size, stride):
         super(AvgPool2dNHWC, self).__init__()
         self.kernel_size, self.stride = kernel_size, stride
 
     def forward(self, x):
-        return engine.boundary(self, x, lambda a: engine.avgpool2d(a, self.kernel_size, self.stride))
+        head = engine.FP32_HEAD and isinstance(x, engine.NHWC) and x.H == self.kernel_size and x.W == self.kernel_size
+        return engine.boundary(self, x, lambda a: engine.avgpool2d(a, self.kernel_size, self.stride, out_fp32=head))
 
 
 class GlobalAvgPool2dNHWC(nn.Module):
@@ -40,7 +42,8 @@ class GlobalAvgPool2dNHWC(nn.Module):
         self.output_size = output_size
 
     def forward(self, x):
-        return engine.boundary(self, x, engine.global_avgpool)
+        head = engine.FP32_HEAD and isinstance(x, engine.NHWC)
+        return engine.boundary(self, x, lambda a: engine.global_avgpool(a, out_fp32=head))
 
 
 class LinearHead(nn.Linear):

@@ -3,9 +3,12 @@ GPU parity, whole nets: `get_model(name)` + the fixture weights, forward through
 golden logits of the imported reference and the oracle.
 
   fp32       : |logits - golden| <= 1e-3, top-1 identical                     (north-star fp32 bound)
-  bf16, fp16 : |logits - quantisation-matched oracle| <= 1e-2, top-1 identical (north-star 16-bit bound, SURVEY 7.3 ii);
-               the raw distance to the fp32 golden is printed and bounded loosely (bf16 0.5, fp16 0.08) - single-pass
-               bf16 operands cannot reach 1e-2 against an fp32 forward (SURVEY Appendix B measured 0.2).
+  bf16, fp16 : |logits - quantisation-matched oracle| <= 1e-2, top-1 identical;
+               AND against the fp32 golden of the imported reference itself: top-1 identical, max |d| <= 1e-2 (the north-star
+               16-bit bound) for fp16 on every net and for bf16 on the nets of BASELINE configs 2 and 4 and the other
+               ResNet-family fixtures - with the fp32 head (engine.FP32_HEAD) - and <= the measured value + 10 % on the
+               depthwise nets, where rounding the WEIGHTS to 8 mantissa bits alone leaves 1.05e-2 (tests/tools/bf16_drift.py:
+               per-source attribution).
 """
 
 import pytest
@@ -14,6 +17,12 @@ import util
 from oracle import refnet
 
 pytestmark = pytest.mark.gpu
+
+# max |bf16 logits - fp32 reference golden| allowed per fixture net: 1e-2 where the north-star bound is met, else measured + 10 %
+# (measured on MI355X with the fp32 head: mobilenetv2_w1 1.55e-2, mobilenetv3 large / small 2.19e-2 / 2.15e-2, efficientnet b0 / b0b
+# 1.27e-2 / 1.30e-2; every other fixture net 4.1e-3 .. 8.6e-3)
+_BF16_VS_GOLDEN = {"mobilenetv2_w1": 1.7e-2, "mobilenetv3_large_w1": 2.4e-2, "mobilenetv3_small_w1": 2.4e-2, "efficientnet_b0": 1.4e-2,
+                   "efficientnet_b0b": 1.45e-2}
 
 
 def _net(name, dtype, dev):
@@ -57,7 +66,9 @@ def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_devic
         name, dtype, err, raw, bool(torch.equal(y.argmax(1), logits.argmax(1)))))
     assert err <= 1e-2
     assert torch.equal(y.argmax(1), ref.argmax(1))
-    assert raw <= (0.5 if dtype == "bf16" else 0.08)
+    assert torch.equal(y.argmax(1), logits.argmax(1)), "top-1 differs from the reference forward"
+    bound = 1e-2 if dtype == "fp16" else _BF16_VS_GOLDEN.get(name, 1e-2)
+    assert raw <= bound, "{} {}: max |d| vs the fp32 reference golden {:.3e} > {:.1e}".format(name, dtype, raw, bound)
 
 
 # BASELINE.json configs 2-4 (+ resnet18 at the same batch): the batches bench.py times. At these sizes every persistent kernel
