@@ -117,26 +117,61 @@ class LaunchTimer(object):
                                        gbs=v[3] / (v[1] * 1e-3) / 1e9) for k, v in per_shape.items()})
 
 
-def cpu_baseline(model, sd_cpu, budget_s=20.0):
-    """The oracle's CPU forward (torch eager fp32 = the ATen path the reference runs), bounded sample, host cores."""
-    from oracle import refnet
-    from pytorchcv_amd.synth import synth_input
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    bs = 32
-    x = synth_input(bs, seed=11)
-    t0 = time.time()
-    refnet.forward(model, sd_cpu, x[:2])                      # warm-up (thread pool, oneDNN primitives)
-    iters, elapsed = 0, 0.0
+def _cpu_rate(fn, images_per_call, budget_s, min_calls=2, max_calls=64):
+    calls, elapsed = 0, 0.0
     t_start = time.time()
-    while iters < 2 or (time.time() - t_start < budget_s and iters < 64):
+    while calls < min_calls or (time.time() - t_start < budget_s and calls < max_calls):
         t1 = time.time()
-        refnet.forward(model, sd_cpu, x)
+        fn()
         elapsed += time.time() - t1
-        iters += 1
-    return dict(value=round(bs * iters / elapsed, 2), unit="images/sec", cores=cores, kind="port",
-                sample="{} forward(s) of batch {} at 224x224, fp32, torch {} eager CPU ops via oracle/refnet.py "
-                       "({:.1f} s incl. warm-up)".format(iters, bs, torch.__version__, time.time() - t0))
+        calls += 1
+    return images_per_call * calls / elapsed, calls
+
+
+def cpu_baseline(model, sd_cpu, budget_s=12.0):
+    """The oracle's CPU forward (torch eager fp32 = the ATen path the reference runs) on the GPU box's host cores, bounded
+    samples: the workload's model on ALL host cores (batch 32) and on one thread (batch 4), plus BASELINE
+    config 1 - resnet18, batch 1, fp32 - on all cores."""
+    from oracle import refnet
+    from pytorchcv_amd.synth import synth_input, synth_state_dict
+    from pytorchcv_amd.model_provider import get_model
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    x = synth_input(32, seed=11)
+    torch.set_num_threads(cores)
+    refnet.forward(model, sd_cpu, x[:2])                      # warm-up (thread pool, oneDNN primitives)
+    rate_all, n_all = _cpu_rate(lambda: refnet.forward(model, sd_cpu, x), 32, budget_s)
+    sd18 = synth_state_dict(get_model("resnet18").state_dict(), seed=1234, calib=calib_for("resnet18"))
+    refnet.forward("resnet18", sd18, x[:1])
+    rate_c1, n_c1 = _cpu_rate(lambda: refnet.forward("resnet18", sd18, x[:1]), 1, 3.0, min_calls=5, max_calls=200)
+    torch.set_num_threads(1)
+    rate_one, n_one = _cpu_rate(lambda: refnet.forward(model, sd_cpu, x[:4]), 4, 6.0, min_calls=1, max_calls=8)
+    torch.set_num_threads(cores)
+    return dict(value=round(rate_all, 2), unit="images/sec", cores=cores, kind="port",
+                one_thread_value=round(rate_one, 3),
+                config1_resnet18_bs1_fp32=dict(value=round(rate_c1, 2), unit="images/sec", cores=cores, ms_per_image=round(1e3 / rate_c1, 2)),
+                sample="{} at 224x224, fp32, torch {} eager CPU ops via oracle/refnet.py: {} forward(s) of batch 32 on {} threads; "
+                       "{} forward(s) of batch 4 on 1 thread; resnet18 batch 1 x {} on {} threads ({:.1f} s in all)".format(
+                           model, torch.__version__, n_all, cores, n_one, n_c1, cores, time.time() - t0))
+
+
+def rocprof_class_us(workload, klass):
+    """Average launch duration of the roofline kernel class from the COMMITTED rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/, single batch lane), beside the live HIP-event figure: (us, file) or (None, None)."""
+    import csv
+    import glob
+    names = {"dense3x3": ("d3q_kernel", "false, 9>"), "depthwise": ("dwconv_kernel", "dwconv5_kernel"),
+             "grouped3x3": ("gconv3x3_kernel",)}.get(klass)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_{}_*kernel_stats*.csv".format(workload.replace("_bs", "_bs")))))
+    if not names or not files:
+        return None, None
+    tot = calls = 0
+    with open(files[-1]) as f:
+        for row in csv.DictReader(f):
+            if any(n in row["Name"] for n in names):
+                tot += int(row["TotalDurationNs"])
+                calls += int(row["Calls"])
+    return (round(tot / calls / 1e3, 2), os.path.relpath(files[-1], ROOT)) if calls else (None, None)
 
 
 def main():
@@ -161,22 +196,23 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus {} needs `python -m torch.distributed.run --nproc-per-node {}`".format(args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("PCV_BENCH_FORCE_DIST") == "1"    # (forcing it at world size 1 rehearses the RCCL calls)
     if use_dist:
+        # the process group comes up first: nothing of ours touches the GPU before RCCL has bound this rank to its device
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
 
     import pytorchcv_amd
     from pytorchcv_amd.model_provider import get_model
     from pytorchcv_amd.synth import synth_state_dict, synth_input
-    from pytorchcv_amd.parallel import ShardedInference, broadcast_module_state
+    from pytorchcv_amd.parallel import ShardedInference, broadcast_module_state, broadcast_packed_state
 
     for kv in filter(None, os.environ.get("PCV_BENCH_TUNE", "").split(",")):       # dev only: "key=value,..." -> pcv_set_tuning
         from pytorchcv_amd import _lib
@@ -191,21 +227,30 @@ def main():
         sd_cpu = synth_state_dict(net.state_dict(), seed=1234, calib=calib_for(model))
         net.load_state_dict(sd_cpu, strict=True)
     net = pytorchcv_amd.set_compute_dtype(net.to(dev), args.dtype)
-    if use_dist:
-        broadcast_module_state(net, src=0)           # RCCL broadcast of rank 0's weights over xGMI
 
     # synthetic N(0,1)-like images: 8 distinct seeded images tiled to the batch (performance is data independent)
     base = synth_input(8, seed=rank).to(dev)
     x = base.repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
+    with torch.no_grad():
+        net(base)                                    # builds and packs every layer (rank 0: the real weights)
+    bcast = None
+    if use_dist:
+        # RCCL broadcast of rank 0's PACKED inference state over xGMI (bf16 arenas + fp32 scale/shift: half the fp32 state;
+        # the receiving ranks do not re-pack)
+        bcast = broadcast_packed_state(net, src=0)
+    with torch.no_grad():
+        y_ref8 = net(base).clone()                   # the 8 distinct images on their own: what every row of the timed batch must equal
     use_graph = args.graph != 0
     fwd = net
     if use_graph:
         from pytorchcv_amd.graph import capture
         try:
             fwd = capture(net, x, own_input=True, lanes=args.lanes if args.lanes > 0 else None)    # ~60 kernel launches replayed by one hipGraphLaunch; x is the static input
-        except Exception as e:                       # noqa: BLE001 - same kernels either way; only the launch mechanism differs
-            print("hipGraph capture failed ({}); falling back to eager launches".format(e), file=sys.stderr)
-            use_graph = False
+        except Exception as e:                       # noqa: BLE001 - a run that cannot capture is not the benchmarked configuration
+            print("bench.py: hipGraph capture failed ({}); rerun with --graph 0 for eager launches".format(e), file=sys.stderr)
+            if use_dist:
+                dist.destroy_process_group()
+            sys.exit(4)
     runner = ShardedInference(fwd)
 
     def step():
@@ -229,7 +274,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert bool(torch.isfinite(y).all())
+    # the timed forward computes what the small-batch forward computes: every row of the full batch (multi-round tile
+    # schedules, graph lanes) equals the 8-image eager result bit for bit; a mismatch fails the run
+    y_local = y[rank * batch:(rank + 1) * batch] if use_dist else y
+    want = y_ref8.repeat((batch + 7) // 8, 1)[:batch]
+    if not bool(torch.isfinite(y_local).all()) or not torch.equal(y_local, want):
+        bad = int((y_local != want).any(1).sum())
+        print("bench.py: {} of {} rows of the timed batch differ from the 8-image forward".format(bad, batch), file=sys.stderr)
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     # HBM traffic of the class from the PMC counters: cannot be read inside this process (rocprofv3 --pmc is its own run);
     # the per-launch figure of the committed passes over this same command travels in profiles/pmc_traffic.json.
@@ -245,18 +299,13 @@ def main():
     # per-launch HIP-event timing of the roofline kernel class (separate pass, not part of `value`)
     roof = None
     if rank == 0:
-        from pytorchcv_amd import engine as _engine
-        fuse_was = _engine.FUSE_UNITS
-        if klass == "depthwise":
-            _engine.FUSE_UNITS = False               # time the depthwise KERNEL on every layer (the fused units bypass it)
-        with torch.no_grad():
+        with torch.no_grad():                        # (the same kernel mix `value` runs: fused units stay fused)
             net(x)                                   # untimed: first use of the per-layer kernels this pass takes (code load, packing)
         torch.cuda.synchronize()
         with LaunchTimer(klass) as lt:
             for _ in range(max(3, min(args.steps, 10))):
                 with torch.no_grad():
                     net(x)                           # eager: events bracket every launch of the class
-        _engine.FUSE_UNITS = fuse_was
         s = lt.summary()
         if s is not None:
             if bound == "mfma":
@@ -265,8 +314,12 @@ def main():
             else:
                 roof = dict(bound="hbm", achieved=round(s["gbs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(s["gbs"] / HBM_PEAK_GBS, 4), traffic=None)
+            rp_us, rp_file = rocprof_class_us(args.workload, klass)
             roof.update(kernel_class=klass, launches_per_step=s["launches"] // max(3, min(args.steps, 10)),
                         avg_launch_us=round(1e3 * s["avg_ms"], 2),
+                        avg_launch_us_source="live: HIP events around every eager launch of the class on the launch stream (this run)",
+                        rocprof_avg_launch_us=rp_us,
+                        rocprof_source=("committed rocprofv3 --kernel-trace --stats of this command with --lanes 1: " + rp_file) if rp_file else None,
                         algorithmic_per_launch=(round(s["flops_per_launch"] / 1e9, 3) if bound == "mfma"
                                                 else round(s["bytes_per_launch"] / 1e6, 3)),
                         algorithmic_unit="GFLOP" if bound == "mfma" else "MB",
@@ -295,11 +348,13 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
-            "config": {"workload": args.workload, "model": model, "per_gpu_batch": batch, "global_batch": world * batch,
+            "config": {"workload": args.workload, "per_gpu_batch": batch, "global_batch": world * batch,
                        "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world),
                        "launch": ("hipGraph replay, {} batch lane(s) as parallel branches".format(fwd.lanes) if use_graph else "eager")},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "weights_broadcast": (dict(messages=bcast[0], bytes=bcast[1], what="packed inference state (RCCL broadcast from rank 0)")
+                                  if bcast else None),
         }
         print(json.dumps(out), flush=True)
     if use_dist:

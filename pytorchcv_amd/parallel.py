@@ -3,14 +3,17 @@
 
     The reference is a single-process library with no distributed code at all; inference on image i
     depends only on the weights, so the path shards by images with NO data-path collective between layers:
-      1. once  : rank 0's weights are broadcast to every rank (flat buckets; ResNet-50 = 102 MB fp32 in 4 buckets - large
-                 messages, because xGMI is point-to-point and ring collectives are per-link bound);
+      1. once  : rank 0's weights are broadcast to every rank in flat buckets of up to 32 MB (large messages, because xGMI is
+                 point-to-point and ring collectives are per-link bound): either the module state (`broadcast_module_state`,
+                 ResNet-50 = 102 MB fp32, every rank then packs for itself) or, for serving, what the kernels actually read -
+                 the PACKED 16-bit weight arenas and the folded fp32 scale/shift arrays (`broadcast_packed_state`, ResNet-50 =
+                 51 MB, nothing is re-packed on the receiving ranks);
       2. / step: rank r runs images [r*B/P, (r+1)*B/P) of the global batch on its own GPU;
       3. / step: an all-gather (or gather to rank 0) of the fp32 logits, 4 KB per image.
     The compute callable is injected, so the same plumbing is exercised on CPU with gloo in the tests.
 """
 
-__all__ = ['shard_range', 'broadcast_module_state', 'ShardedInference']
+__all__ = ['shard_range', 'broadcast_module_state', 'broadcast_packed_state', 'packed_state_tensors', 'ShardedInference']
 
 import torch
 import torch.distributed as dist
@@ -25,15 +28,15 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = _BUCKET_BYTES):
-    """Make every rank's parameters and buffers equal to rank `src`'s, with a few large broadcasts per dtype."""
+def _broadcast_buckets(tensors, src, group, bucket_bytes):
+    """`tensors` (same order and shapes on every rank) become equal to rank `src`'s, a few large broadcasts per dtype."""
     by_dtype = {}
-    for _, t in sorted(module.state_dict().items()):
+    for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    n_msgs = 0
-    for dtype, tensors in by_dtype.items():
+    n_msgs = n_bytes = 0
+    for dtype, group_tensors in by_dtype.items():
         bucket, size = [], 0
-        for t in tensors + [None]:
+        for t in group_tensors + [None]:
             if t is not None and (size == 0 or size + t.numel() * t.element_size() <= bucket_bytes):
                 bucket.append(t)
                 size += t.numel() * t.element_size()
@@ -46,8 +49,69 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, bu
                     b.copy_(flat[off:off + b.numel()].view_as(b))
                     off += b.numel()
             n_msgs += 1
+            n_bytes += size
             bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
-    return n_msgs
+    return n_msgs, n_bytes
+
+
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = _BUCKET_BYTES):
+    """Make every rank's parameters and buffers equal to rank `src`'s, with a few large broadcasts per dtype."""
+    return _broadcast_buckets([t for _, t in sorted(module.state_dict().items())], src, group, bucket_bytes)[0]
+
+
+def packed_state_tensors(module: torch.nn.Module):
+    """What the kernels read at inference time, in module order: (tensors, refresh hooks).
+      * per convolution / linear layer: the packed weight blob in the compute type and the folded fp32 scale / shift
+        (`engine.ConvRunner`), per stand-alone BatchNorm the folded scale / shift (`engine.BnActRunner`);
+      * the fp32 source tensors of everything that is read UNPACKED at run time: modules without a runner (SE excitation
+        matrices and biases), and convolutions whose weights are folded into an SE squeeze map (`ConvRunner.squeezed_excite`
+        re-derives that map from the fp32 weights: its cache is dropped by the hook so that it is rebuilt from the received
+        tensors).
+    Every runner must already be built (one forward of the net on any input of the serving shape does that)."""
+    from . import engine
+    tensors, hooks = [], []
+    owned = set()
+
+    def runners_of(m):
+        for attr in sorted(vars(m)):
+            if not attr.startswith("_pcv"):
+                continue
+            v = vars(m)[attr]
+            items = [v] if not isinstance(v, (dict, list, tuple)) else (
+                [v[k] for k in sorted(v, key=repr)] if isinstance(v, dict) else list(v))
+            for r in items:
+                if isinstance(r, (engine.ConvRunner, engine.BnActRunner)):
+                    yield r
+
+    for _, m in sorted(module.named_modules()):
+        for r in runners_of(m):
+            if r.scale is None or r.shift is None:
+                raise RuntimeError("packed state requested before the first forward built every runner")
+            if getattr(r, "packed", None) is not None:
+                tensors.append(r.packed)
+            tensors += [r.scale, r.shift]
+            if getattr(r, "_sq_key", None) is not None:              # SE squeeze folded through this convolution: fp32 too
+                hooks.append(lambda r=r: setattr(r, "_sq_key", None))
+                continue
+            src = r._sources() if isinstance(r, engine.ConvRunner) else (r.bn.weight, r.bn.bias, r.bn.running_mean, r.bn.running_var)
+            owned.update(id(t) for t in src if t is not None)
+    for _, t in sorted(module.state_dict(keep_vars=True).items()):
+        if id(t) not in owned and t.dtype.is_floating_point:
+            tensors.append(t.data)
+    return tensors, hooks
+
+
+def broadcast_packed_state(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = _BUCKET_BYTES):
+    """Serving-time weight distribution: rank `src`'s packed inference state (see `packed_state_tensors`) overwrites every
+    other rank's. Half the bytes of the fp32 state for a 16-bit net, and the receiving ranks do not pack. After it, the fp32
+    parameters of convolutions on ranks != src are NOT those of `src` (only their packed form is): a later
+    `load_state_dict` / `set_compute_dtype` re-packs from whatever the module then holds, as on a single GPU.
+    Returns (messages, bytes)."""
+    tensors, hooks = packed_state_tensors(module)
+    out = _broadcast_buckets(tensors, src, group, bucket_bytes)
+    for h in hooks:
+        h()
+    return out
 
 
 class ShardedInference(object):

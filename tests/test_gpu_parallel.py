@@ -1,0 +1,81 @@
+"""GPU, world size 1, RCCL: the multi-GPU code path of bench.py / pytorchcv_amd.parallel rehearsed on the one GPU a test box has -
+process group on backend "nccl" (= RCCL), weight broadcast (module state and packed state), hipGraph forward, logits all-gather.
+Nothing here measures scaling (no multi-GPU node is available to the tests); it proves the collectives are issued on the
+right tensors and change nothing at world size 1, and that the packed broadcast really carries what the kernels read."""
+
+import os
+import pytest
+import torch
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rccl_group(cuda_device):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=cuda_device)
+    yield dist
+    dist.destroy_process_group()
+
+
+def _net(name, dev):
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model
+    net = get_model(name).eval()
+    net.load_state_dict(util.model_state(name, net.state_dict()), strict=True)
+    return pytorchcv_amd.set_compute_dtype(net.to(dev), "bf16")
+
+
+def test_rccl_rehearsal_broadcast_graph_allgather(rccl_group, cuda_device):
+    from pytorchcv_amd.parallel import ShardedInference, broadcast_module_state
+    from pytorchcv_amd.graph import capture
+    net = _net("resnet18", cuda_device)
+    _, ids = util.model_golden("resnet18")
+    x = util.images(ids).to(cuda_device).repeat(16, 1, 1, 1).contiguous()            # 64 images: two graph lanes
+    with torch.no_grad():
+        y_local = net(x).clone()
+        assert broadcast_module_state(net, src=0) >= 1                                # RCCL broadcast of the fp32 state
+        g = capture(net, x)                                                           # re-packs nothing: same tensors
+        runner = ShardedInference(g)
+        y = runner.gather_all(runner.run_local(x))                                    # all_gather_into_tensor on RCCL
+    torch.cuda.synchronize()
+    assert y.shape == y_local.shape and torch.equal(y, y_local)
+    assert torch.equal(runner(x), y_local)                                            # shard + run + gather in one call
+
+
+@pytest.mark.parametrize("name", ["resnet50", "seresnet50", "preresnet18"])
+def test_packed_state_broadcast_carries_what_the_kernels_read(name, rccl_group, cuda_device):
+    """broadcast_packed_state: the packed arenas + folded constants (+ fp32 tensors read unpacked: SE matrices) are the
+    complete inference state. A second net whose fp32 convolution weights are garbage gives the first net's logits once it
+    holds the first net's packed state; the bytes on the wire are about half the fp32 state for a bf16 net."""
+    from pytorchcv_amd import parallel
+    import pytorchcv_amd
+    from pytorchcv_amd.model_provider import get_model
+    a = _net(name, cuda_device)
+    b = pytorchcv_amd.set_compute_dtype(get_model(name).eval().to(cuda_device), "bf16")  # random init: different weights
+    _, ids = util.model_golden(name)
+    x = util.images(ids).to(cuda_device)
+    with torch.no_grad():
+        ya = a(x).clone()
+        yb0 = b(x).clone()                                                            # builds b's runners (packs garbage)
+    assert not torch.equal(ya, yb0)
+    ta, _ = parallel.packed_state_tensors(a)
+    tb, hooks = parallel.packed_state_tensors(b)
+    assert [(t.shape, t.dtype) for t in ta] == [(t.shape, t.dtype) for t in tb]
+    with torch.no_grad():
+        for s, d in zip(ta, tb):                                                      # what a broadcast from a's rank would deliver
+            d.copy_(s)
+        for h in hooks:
+            h()
+        yb = b(x).clone()
+    assert torch.equal(ya, yb)
+    msgs, nbytes = parallel.broadcast_packed_state(b, src=0)                          # and the collective itself, on RCCL
+    fp32_state = sum(t.numel() * t.element_size() for t in a.state_dict().values())
+    assert msgs >= 1 and nbytes == sum(t.numel() * t.element_size() for t in tb)
+    if name == "resnet50":
+        assert 0.45 * fp32_state < nbytes < 0.60 * fp32_state, (nbytes, fp32_state)  # 51 MB of packed state vs 102 MB of fp32
+    with torch.no_grad():
+        assert torch.equal(b(x), ya)

@@ -86,3 +86,35 @@ def test_shard_range_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorchcv_amd import parallel
+    g = torch.Generator().manual_seed(100 + rank)                 # every rank starts with different contents
+    tensors = [torch.randn(n, generator=g) for n in (7, 1000, 3, 50000)] + \
+              [torch.randint(0, 255, (n,), generator=g, dtype=torch.uint8) for n in (17, 40000, 5)]
+    msgs, nbytes = parallel._broadcast_buckets(tensors, 0, None, bucket_bytes=64 << 10)      # 64 KB buckets: several messages
+    torch.save(dict(tensors=tensors, msgs=msgs, nbytes=nbytes), os.path.join(out_dir, "b{}.pt".format(rank)))
+    dist.destroy_process_group()
+
+
+def test_bucketed_broadcast_mixed_dtypes(tmp_path):
+    """The flat-bucket broadcast behind broadcast_module_state / broadcast_packed_state: mixed dtypes (the packed arenas are
+    uint8 blobs, the folded BN constants fp32), tensors larger than a bucket, several messages - every rank ends up with rank
+    0's contents and the byte count is the sum of the tensors."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "b0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "b1.pt"))
+    g = torch.Generator().manual_seed(100)
+    want = [torch.randn(n, generator=g) for n in (7, 1000, 3, 50000)] + \
+           [torch.randint(0, 255, (n,), generator=g, dtype=torch.uint8) for n in (17, 40000, 5)]
+    for a, b, w in zip(r0["tensors"], r1["tensors"], want):
+        assert torch.equal(a, w) and torch.equal(b, w)
+    assert r0["nbytes"] == r1["nbytes"] == sum(t.numel() * t.element_size() for t in want)
+    assert r0["msgs"] == r1["msgs"] == 3        # fp32: {7, 1000, 3} + {50000 alone: larger than a bucket}; uint8: one bucket
