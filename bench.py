@@ -128,6 +128,29 @@ def _cpu_rate(fn, images_per_call, budget_s, min_calls=2, max_calls=64):
     return images_per_call * calls / elapsed, calls
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity, cut down to the cgroup CPU quota where one is set (a
+    one-GPU box of the pool is a 16-CPU share of a 256-thread host; 256 OpenMP threads on that share ran 40x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    cap = int(os.environ.get("PCV_BENCH_CPU_THREADS", "0"))
+    return min(n, cap) if cap > 0 else n
+
+
 def cpu_baseline(model, sd_cpu, budget_s=12.0):
     """The oracle's CPU forward (torch eager fp32 = the ATen path the reference runs) on the GPU box's host cores, bounded
     samples: the workload's model on ALL host cores (batch 32) and on one thread (batch 4), plus BASELINE
@@ -135,7 +158,7 @@ def cpu_baseline(model, sd_cpu, budget_s=12.0):
     from oracle import refnet
     from pytorchcv_amd.synth import synth_input, synth_state_dict
     from pytorchcv_amd.model_provider import get_model
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t0 = time.time()
     x = synth_input(32, seed=11)
     torch.set_num_threads(cores)
@@ -147,7 +170,7 @@ def cpu_baseline(model, sd_cpu, budget_s=12.0):
     torch.set_num_threads(1)
     rate_one, n_one = _cpu_rate(lambda: refnet.forward(model, sd_cpu, x[:4]), 4, 6.0, min_calls=1, max_calls=8)
     torch.set_num_threads(cores)
-    return dict(value=round(rate_all, 2), unit="images/sec", cores=cores, kind="port",
+    return dict(value=round(rate_all, 2), unit="images/sec", cores=cores, kind="port", host_logical_cpus=os.cpu_count(),
                 one_thread_value=round(rate_one, 3),
                 config1_resnet18_bs1_fp32=dict(value=round(rate_c1, 2), unit="images/sec", cores=cores, ms_per_image=round(1e3 / rate_c1, 2)),
                 sample="{} at 224x224, fp32, torch {} eager CPU ops via oracle/refnet.py: {} forward(s) of batch 32 on {} threads; "
