@@ -33,6 +33,7 @@ struct DwParams {
     int nseg;             // ceil(Ho / TH)
     int act, post_act;
     long total;           // N * nseg * Wo * C8
+    int flags;            // tuning: bit 0 = non-temporal output stores
 };
 
 template <int DT> __device__ __forceinline__ void load8(const void* base, size_t eidx, float (&v)[8]) {
@@ -47,7 +48,7 @@ template <int DT> __device__ __forceinline__ void load8(const void* base, size_t
         for (int e = 0; e < 4; ++e) unpack2<DT>(r[e], v[2 * e], v[2 * e + 1]);
     }
 }
-template <int DT> __device__ __forceinline__ void store8(void* base, size_t eidx, const float (&v)[8]) {
+template <int DT> __device__ __forceinline__ void store8(void* base, size_t eidx, const float (&v)[8], bool nt = false) {
     if constexpr (DT == PCV_F32) {
         float* p = reinterpret_cast<float*>(base) + eidx;
         *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
@@ -56,7 +57,9 @@ template <int DT> __device__ __forceinline__ void store8(void* base, size_t eidx
         u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + eidx) = o;
+        u32x4* q = reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(base) + eidx);
+        if (nt) __builtin_nontemporal_store(o, q);      // (launch-uniform) streaming store: the line is not kept for a reader that never comes
+        else *q = o;
     }
 }
 
@@ -109,9 +112,9 @@ template <int DT, int CPT> __device__ __forceinline__ void loadn(const void* bas
         unpack2<DT>(r[1], v[2], v[3]);
     }
 }
-template <int DT, int CPT> __device__ __forceinline__ void storen(void* base, size_t eidx, const float (&v)[CPT]) {
+template <int DT, int CPT> __device__ __forceinline__ void storen(void* base, size_t eidx, const float (&v)[CPT], bool nt = false) {
     if constexpr (CPT == 8) {
-        store8<DT>(base, eidx, v);
+        store8<DT>(base, eidx, v, nt);
     } else if constexpr (DT == PCV_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + eidx) = (f32x4){v[0], v[1], v[2], v[3]};
     } else {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
                 if (p.post_act != PCV_ACT_NONE) {
                     if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
                 }
-                storen<DT, CPT>(p.y, eoff, v);
+                storen<DT, CPT>(p.y, eoff, v, (p.flags & 1) != 0);
                 ++ho;
                 hi += S;
             }
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
                                 if (p.post_act != PCV_ACT_NONE) {
                                     if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
                                 }
-                                storen<DT, CPT>(p.y, eoff, v);
+                                storen<DT, CPT>(p.y, eoff, v, (p.flags & 1) != 0);
                             }
 #pragma unroll
                             for (int e = 0; e < NV; ++e) acc[slot][e] = (f32x2){0.f, 0.f};

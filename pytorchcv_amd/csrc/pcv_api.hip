@@ -35,6 +35,8 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
+    int dw_flags = 0;           // tuning: bit 0 = non-temporal stores in the depthwise kernels
+    int dw_th = 0;              // tuning: rows per thread of the depthwise kernel (0 = automatic)
     int max_blocks = 0;         // test-only: cap on every persistent grid (0 = resident blocks), so that small fixtures walk several
                                 // tiles per block through the cross-tile pipelines (pcv_set_tuning("max_blocks", n))
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
@@ -630,6 +632,8 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
+    else if (k == "dw_th") ctx->dw_th = value;
+    else if (k == "dw_flags") ctx->dw_flags = value;
     else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;
     else if (k == "dbg_hi") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFFull) | ((unsigned long long)(unsigned)value << 32);
     else if (k == "wstat") ctx->use_wstat = value;
@@ -1101,11 +1105,13 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     if (nseg < 1) nseg = 1;
     int TH = (p.Ho + nseg - 1) / nseg;
     if (TH < 4) TH = p.Ho < 4 ? p.Ho : 4;
+    if (ctx->dw_th > 0) TH = ctx->dw_th < p.Ho ? ctx->dw_th : p.Ho;
     p.TH = TH;
     p.nseg = (p.Ho + TH - 1) / TH;
     p.act = d->act;
     p.post_act = d->post_act;
     p.total = cols * p.nseg;
+    p.flags = ctx->dw_flags;
     const unsigned grid = (unsigned)((p.total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (d->dtype == PCV_BF16) launch_dw<PCV_BF16>(*d, p, grid, s);
@@ -1233,8 +1239,9 @@ int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* res
         return fail(ctx, PCV_ERR_INVALID, "pcv_se_scale: bad argument (C must be a multiple of 8)");
     const long total8 = (long)N * HW * (C / 8);
     long blocks = (total8 + 255) / 256;
-    const long cap = (long)block_slots(ctx, 16);
-    if (blocks > cap) blocks = cap;
+    // one short-lived block per 256 chunks: a streaming kernel of fresh blocks reads 6.2 TB/s where grid-stride loops of resident
+    // blocks read 4.4 (tests/tools/micro/copy_bw2.cpp); the cap only exists for the multi-round tests (max_blocks)
+    if (ctx->max_blocks > 0 && blocks > ctx->max_blocks) blocks = ctx->max_blocks;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
     else if (dtype == PCV_F16) se_scale_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
@@ -1526,8 +1533,7 @@ int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shi
         return fail(ctx, PCV_ERR_INVALID, "pcv_bn_act: bad argument (C and x_cpitch must be multiples of 8, x_cpitch >= C)");
     const long total8 = rows * (C / 8);
     long blocks = (total8 + 255) / 256;
-    const long cap = (long)block_slots(ctx, 16);
-    if (blocks > cap) blocks = cap;
+    if (ctx->max_blocks > 0 && blocks > ctx->max_blocks) blocks = ctx->max_blocks;       // (see pcv_se_scale)
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
     else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
