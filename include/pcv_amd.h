@@ -158,6 +158,15 @@ int pcv_channel_slice(pcv_ctx* ctx, const void* x, void* y, long rows, int C, in
  * y[.., 2i] = a[.., i], y[.., 2i+1] = b[.., i], i < Ch. */
 int pcv_channel_interleave2(pcv_ctx* ctx, const void* a, const void* b, void* y, long rows, int Ch, int a_cpitch,
                             int b_cpitch, int y_cpitch, int dtype, void* stream);
+/* torch.cat(..., dim=1) of `Concurrent` / `SequentialConcurrent` (common/arch.py:58-131) in its copy form: y[rows, y_offset + c] =
+ * x[rows, c], c < C; channel counts, offset and pitches are multiples of 8. (A branch that ends in a convolution writes its
+ * slice itself: pcv_conv2d_fused with y pointing at the slice and d->y_cpitch set - no copy at all.) */
+int pcv_channel_concat(pcv_ctx* ctx, const void* x, void* y, long rows, int C, int x_cpitch, int y_cpitch, int y_offset,
+                       int dtype, void* stream);
+/* F.interpolate of `InterpolationBlock` (common/tutti.py:194-264): x NHWC [N,H,W,C] -> y NHWC [N,Ho,Wo,C]; bilinear != 0:
+ * mode "bilinear" with the given align_corners, else mode "nearest". fp32 arithmetic, ATen's source-coordinate rules. */
+int pcv_interpolate(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int bilinear,
+                    int align_corners, int dtype, void* stream);
 /* nn.AvgPool2d(k, stride=s), no padding (resnet.py:316-318, mobilenetv2.py:134-136); k == H == W is the
  * global-average-pool of the classifier tail. fp32 accumulation. */
 int pcv_avgpool2d(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int k, int s,

@@ -11,7 +11,7 @@
     shufflenetv2.py:17-120 (ShuffleUnit, ShuffleInitBlock).
 """
 
-__all__ = ['block_forward']
+__all__ = ['block_forward', 'f4_block_forward']
 
 import torch
 import torch.nn.functional as F
@@ -127,3 +127,47 @@ def block_forward(kind: str, kwargs: dict, sd: dict, x: torch.Tensor, quant: str
             y = conv_block(sd, "body.conv2.", y, stride=stride, padding=1, groups=kw["cardinality"], q=q)
             return conv_block(sd, "body.conv3.", y, act=None, q=q, residual=identity, post_act="relu")
     raise NotImplementedError(kind)
+
+
+# ---- branch / merge containers, interpolation, stand-alone BN + activation ------------------------------------
+def f4_block_forward(name: str, sd: dict, x: torch.Tensor, quant: str | None = None) -> torch.Tensor:
+    """The cases of tests/golden/cases.F4_CASES (structure: cases.build_f4_block) restated over a state_dict:
+    Concurrent / SequentialConcurrent.forward (common/arch.py:87-99, 121-131), NormActivation.forward (common/tutti.py:188-191),
+    InterpolationBlock.forward (tutti.py:232-246), channel_shuffle (tutti.py:267-291). 16-bit mode: every stored tensor is
+    rounded where the GPU path stores it (each branch result / the merged sum once)."""
+    q = Quant(quant)
+    pool = lambda t: F.max_pool2d(t, kernel_size=3, stride=1, padding=1)       # noqa: E731 - nn.MaxPool2d(3, 1, 1) of the cases
+    with torch.no_grad():
+        x = q.r(x.float())
+        if name == "norm_activation":
+            return bn_act(sd, "bn.", x, q=q, act="relu")
+        if name == "interp_bilinear_up2":
+            return q.r(F.interpolate(x, size=(2 * x.shape[2], 2 * x.shape[3]), mode="bilinear", align_corners=True))
+        if name == "interp_bilinear_noalign_size":
+            return q.r(F.interpolate(x, size=(13, 10), mode="bilinear", align_corners=False))
+        if name == "interp_nearest_up2":
+            return q.r(F.interpolate(x, scale_factor=2, mode="nearest"))
+        if name == "interp_bilinear_down2":
+            return q.r(F.interpolate(x, size=(x.shape[2] // 2, x.shape[3] // 2), mode="bilinear", align_corners=True))
+        if name == "concurrent_cat":
+            b1 = conv_block(sd, "branch1.", x, q=q)
+            b2 = conv_block(sd, "branch2.", x, padding=1, q=q)
+            b3 = conv_block(sd, "branch3.conv2.", conv_block(sd, "branch3.conv1.", x, q=q), padding=1, q=q)
+            return torch.cat((b1, b2, b3), dim=1)
+        if name == "concurrent_cat_pool":
+            b1 = conv_block(sd, "branch1.", x, padding=1, q=q)
+            b2 = conv_block(sd, "branch2.conv.", pool(x), q=q)
+            return torch.cat((b1, b2, pool(x)), dim=1)
+        if name == "concurrent_sum":
+            # GPU path: branch1 stored; branch2's convolution takes it as the epilogue residual (stored once); + pool, one add pass
+            acc = conv_block(sd, "branch1.", x, q=q)
+            acc = conv_block(sd, "branch2.", x, padding=1, q=q, residual=acc)
+            return q.r(acc + pool(x))
+        if name == "seq_concurrent":
+            y1 = conv_block(sd, "conv1.", x, padding=1, q=q)
+            y2 = conv_block(sd, "conv2.", y1, padding=1, q=q)
+            return torch.cat((x, y1, y2), dim=1)
+        if name == "channel_shuffle_g2":
+            n, c, h, w = x.shape
+            return x.view(n, 2, c // 2, h, w).transpose(1, 2).contiguous().view(n, c, h, w)
+    raise KeyError(name)

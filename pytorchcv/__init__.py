@@ -10,6 +10,7 @@
     file only so that the entry point named by the drop-in contract can be read where a maintainer looks for it.
 """
 
+import os
 import sys
 import importlib
 import importlib.abc
@@ -19,6 +20,7 @@ import pytorchcv_amd as _impl
 
 __version__ = getattr(_impl, "__version__", "0.0.73+amd")
 _PREFIX, _TARGET = __name__ + ".", _impl.__name__ + "."
+_HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
@@ -27,6 +29,9 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path=None, target=None):
         if not fullname.startswith(_PREFIX):
             return None
+        rel = fullname[len(_PREFIX):].replace(".", os.sep)
+        if os.path.exists(os.path.join(_HERE, rel + ".py")) or os.path.isdir(os.path.join(_HERE, rel)):
+            return None                                          # a file of this package (model_provider.py): the stock finders load it
         real = _TARGET + fullname[len(_PREFIX):]
         try:
             if importlib.util.find_spec(real) is None:
@@ -42,7 +47,9 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+# in FRONT of the path finders: the aliased parent package's __path__ is pytorchcv_amd's, where the stock finder would load a
+# second copy of a submodule under the `pytorchcv.` name (two sets of classes) before this finder is asked
 if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
-    sys.meta_path.append(_AliasFinder())
+    sys.meta_path.insert(0, _AliasFinder())
 
 set_compute_dtype = _impl.set_compute_dtype

@@ -61,6 +61,8 @@ _SIGS = {
     "pcv_maxpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_channel_slice": (_I, [_VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _I, _VP]),
     "pcv_channel_interleave2": (_I, [_VP, _VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _I, _VP]),
+    "pcv_channel_concat": (_I, [_VP, _VP, _VP, ctypes.c_long, _I, _I, _I, _I, _I, _VP]),
+    "pcv_interpolate": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_avgpool2d": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_global_avgpool": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),
     "pcv_gemm_bias": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _I, _VP]),

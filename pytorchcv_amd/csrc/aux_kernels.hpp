@@ -400,6 +400,67 @@ __global__ __launch_bounds__(256) void channel_slice_kernel(const void* __restri
     for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? load_elem<DT>(x, (size_t)row * xpitch + off + c0 + e) : 0.f;
     store8<DT>(y, (size_t)row * ypitch + c0, v);
 }
+// torch.cat along channels, the copy form (arch.py:93-94 when a branch cannot write its slice itself): y[row, off + c] = x[row, c],
+// c < C. C, off and both pitches are multiples of 8: one thread = one 16-byte chunk.
+template <int DT>
+__global__ __launch_bounds__(256) void channel_concat_kernel(const void* __restrict__ x, void* __restrict__ y, long rows, int C,
+                                                            int xpitch, int ypitch, int off) {
+    const int C8 = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C8) return;
+    const long row = i / C8;
+    const int c0 = (int)(i - row * C8) * 8;
+    constexpr int ES = Elem<DT>::BYTES;
+    const char* src = reinterpret_cast<const char*>(x) + ((size_t)row * xpitch + c0) * ES;
+    char* dst = reinterpret_cast<char*>(y) + ((size_t)row * ypitch + off + c0) * ES;
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    if constexpr (ES == 4) *reinterpret_cast<u32x4*>(dst + 16) = *reinterpret_cast<const u32x4*>(src + 16);
+}
+
+// F.interpolate(mode = "bilinear" | "nearest", align_corners) of InterpolationBlock (tutti.py:232-246) on NHWC: one thread = one
+// output pixel x 8 channels, fp32 arithmetic. Source coordinates as ATen computes them: align_corners: dst * (in - 1) / (out - 1);
+// otherwise max(0, (dst + 0.5) * in / out - 0.5); nearest: min(floor(dst * in / out), in - 1).
+template <int DT>
+__global__ __launch_bounds__(256) void interpolate_kernel(const void* __restrict__ x, void* __restrict__ y, int N, int H, int W,
+                                                         int C, int Ho, int Wo, int bilinear, int align_corners) {
+    const int C8 = C / 8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * Ho * Wo * C8) return;
+    const int c0 = (int)(i % C8) * 8;
+    long t = i / C8;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float v[8];
+    if (!bilinear) {
+        const float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+        const int hi = min((int)floorf(ho * sh), H - 1), wi = min((int)floorf(wo * sw), W - 1);
+        load8<DT>(x, (((size_t)n * H + hi) * W + wi) * C + c0, v);
+    } else {
+        float fh, fw;
+        if (align_corners) {
+            fh = Ho > 1 ? ho * ((float)(H - 1) / (float)(Ho - 1)) : 0.f;
+            fw = Wo > 1 ? wo * ((float)(W - 1) / (float)(Wo - 1)) : 0.f;
+        } else {
+            fh = fmaxf(((float)ho + 0.5f) * ((float)H / (float)Ho) - 0.5f, 0.f);
+            fw = fmaxf(((float)wo + 0.5f) * ((float)W / (float)Wo) - 0.5f, 0.f);
+        }
+        const int h0 = min((int)fh, H - 1), w0 = min((int)fw, W - 1);
+        const int h1 = min(h0 + 1, H - 1), w1 = min(w0 + 1, W - 1);
+        const float lh = fh - (float)h0, lw = fw - (float)w0;
+        float a[8], b[8], c[8], d[8];
+        load8<DT>(x, (((size_t)n * H + h0) * W + w0) * C + c0, a);
+        load8<DT>(x, (((size_t)n * H + h0) * W + w1) * C + c0, b);
+        load8<DT>(x, (((size_t)n * H + h1) * W + w0) * C + c0, c);
+        load8<DT>(x, (((size_t)n * H + h1) * W + w1) * C + c0, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = (1.f - lh) * ((1.f - lw) * a[e] + lw * b[e]) + lh * ((1.f - lw) * c[e] + lw * d[e]);
+    }
+    store8<DT>(y, (size_t)i * 8, v);
+}
+
 // torch.cat((a, b), dim=1) followed by channel_shuffle(groups = 2): y[.., 2i] = a[.., i], y[.., 2i + 1] = b[.., i], i < Ch.
 template <int DT>
 __global__ __launch_bounds__(256) void channel_interleave2_kernel(const void* __restrict__ a, const void* __restrict__ b,

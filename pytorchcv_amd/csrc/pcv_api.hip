@@ -1429,6 +1429,39 @@ int pcv_channel_slice(pcv_ctx* ctx, const void* x, void* y, long rows, int C, in
     return PCV_OK;
 }
 
+int pcv_channel_concat(pcv_ctx* ctx, const void* x, void* y, long rows, int C, int x_cpitch, int y_cpitch, int y_offset, int dtype,
+                       void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !y || rows <= 0 || C <= 0 || C % 8 != 0 || x_cpitch < C || x_cpitch % 8 != 0 || y_offset < 0 || y_offset % 8 != 0 ||
+        y_cpitch < y_offset + C || y_cpitch % 8 != 0 || !dtype_ok(dtype) || !aligned16(x) || !aligned16(y))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_channel_concat: bad argument (C, offset and pitches must be multiples of 8, y must hold the slice)");
+    const long total = rows * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) channel_concat_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, rows, C, x_cpitch, y_cpitch, y_offset);
+    else if (dtype == PCV_F16) channel_concat_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, rows, C, x_cpitch, y_cpitch, y_offset);
+    else channel_concat_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, rows, C, x_cpitch, y_cpitch, y_offset);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_interpolate(pcv_ctx* ctx, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, int bilinear,
+                    int align_corners, int dtype, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || Ho <= 0 || Wo <= 0 || !dtype_ok(dtype))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_interpolate: bad argument (C must be a multiple of 8)");
+    const long total = (long)N * Ho * Wo * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PCV_BF16) interpolate_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, bilinear, align_corners);
+    else if (dtype == PCV_F16) interpolate_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, bilinear, align_corners);
+    else interpolate_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, N, H, W, C, Ho, Wo, bilinear, align_corners);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
 int pcv_channel_interleave2(pcv_ctx* ctx, const void* a, const void* b, void* y, long rows, int Ch, int a_cpitch, int b_cpitch,
                             int y_cpitch, int dtype, void* stream) {
     if (!ctx) return PCV_ERR_INVALID;

@@ -6,7 +6,7 @@
 
 __all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'from_nchw', 'to_nchw', 'ConvRunner',
            'BnActRunner', 'maxpool2d', 'avgpool2d', 'global_avgpool', 'se_forward', 'channel_slice', 'cat_shuffle2', 'act_code',
-           'boundary', 'round8']
+           'boundary', 'round8', 'channel_concat_into', 'interpolate', 'add']
 
 import os
 import ctypes
@@ -463,6 +463,42 @@ def channel_slice(x: NHWC, offset: int, count: int) -> NHWC:
     _lib.check(_lib.lib().pcv_channel_slice(ctx, _ptr(x.t), _ptr(y), x.N * x.H * x.W, count, offset, x.cpitch, cp,
                                             _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
     return NHWC(y, x.N, x.H, x.W, count, cpitch=cp)
+
+
+def channel_concat_into(x: NHWC, buf: torch.Tensor, coff: int):
+    """buf[:, :, :, coff:coff + x.C] = x (the copy form of torch.cat along channels; a convolution writes its slice itself
+    through `ConvRunner.run(out=(buf, coff))`). x.C and coff must be multiples of 8."""
+    if x.wpitch != x.W or x.C % 8 or coff % 8 or tuple(buf.shape[:3]) != (x.N, x.H, x.W) or buf.dtype != x.dtype or \
+            coff + x.C > buf.shape[3] or not buf.is_contiguous():
+        raise RuntimeError("channel concatenation needs channel counts / offsets that are multiples of 8 and equal maps")
+    ctx = _ctx(x.device)
+    _lib.check(_lib.lib().pcv_channel_concat(ctx, _ptr(x.t), _ptr(buf), x.N * x.H * x.W, x.C, x.cpitch, int(buf.shape[3]), coff,
+                                             _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
+
+
+def interpolate(x: NHWC, out_size, bilinear: bool, align_corners: bool) -> NHWC:
+    """F.interpolate(size=out_size, mode="bilinear" | "nearest", align_corners) on an NHWC handle (pcv_interpolate)."""
+    if not x.dense:
+        raise RuntimeError("interpolation on a padded handle")
+    Ho, Wo = int(out_size[0]), int(out_size[1])
+    y = torch.empty((x.N, Ho, Wo, x.cpitch), dtype=x.dtype, device=x.device)
+    ctx = _ctx(x.device)
+    _lib.check(_lib.lib().pcv_interpolate(ctx, _ptr(x.t), _ptr(y), x.N, x.H, x.W, x.cpitch, Ho, Wo, 1 if bilinear else 0,
+                                          1 if align_corners else 0, _CODE_OF_TORCH[x.dtype], _stream(x.device)), ctx)
+    return NHWC(y, x.N, Ho, Wo, x.C, cpitch=x.cpitch)
+
+
+def add(a: NHWC, b: NHWC, post_act: int = 0) -> NHWC:
+    """post_act(a + b) as one pass (pcv_se_scale with a unit gate): the fallback of a summing `Concurrent` whose branch does not
+    end in a convolution (a convolution takes the running sum as its epilogue residual instead)."""
+    if a.t.shape != b.t.shape or a.dtype != b.dtype or not a.dense:
+        raise RuntimeError("add: operands do not match")
+    ones = torch.ones((a.N, a.cpitch), dtype=torch.float32, device=a.device)
+    y = torch.empty_like(a.t)
+    ctx = _ctx(a.device)
+    _lib.check(_lib.lib().pcv_se_scale(ctx, _ptr(a.t), _ptr(ones), _ptr(b.t), _ptr(y), a.N, a.H * a.W, a.cpitch, post_act,
+                                       _CODE_OF_TORCH[a.dtype], _stream(a.device)), ctx)
+    return NHWC(y, a.N, a.H, a.W, a.C, cpitch=a.cpitch)
 
 
 def cat_shuffle2(a: NHWC, b: NHWC, half: int) -> NHWC:

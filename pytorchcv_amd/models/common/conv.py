@@ -69,13 +69,15 @@ class ConvBlock(nn.Module):
                 assert isinstance(self.activ, nn.Module)
         self._pcv_runner = None
 
-    def forward(self, x, residual=None, post_act=None, pad4=None):
+    def forward(self, x, residual=None, post_act=None, pad4=None, out=None):
+        """`out` = (NHWC buffer [N, Ho, Wo, Ctot], channel offset): write the result into that channel slice (a concatenation
+        without the copy: common/arch.py `Concurrent`); returns None then."""
         if self._pcv_runner is None:
             self._pcv_runner = engine.ConvRunner(self.conv, self.bn if self.normalize else None, pad4=self._pad4)
         act = engine.act_code(self.activ) if self.activate else 0
         pact = engine.act_code(post_act)
         return engine.boundary(self, x, lambda a: self._pcv_runner.run(a, act=act, residual=residual, post_act=pact,
-                                                                       pad4=pad4))
+                                                                       pad4=pad4, out=out))
 
 
 def conv_block_maxpool(block, x, pool):

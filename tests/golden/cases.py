@@ -129,3 +129,67 @@ BLOCK_CASES = [
          kwargs=dict(in_channels=24, out_channels=116, downsample=True, use_se=False, use_residual=False), x=(2, 24, 28, 28)),
     dict(name="shuffle_init_block", kind="ShuffleInitBlock", kwargs=dict(in_channels=3, out_channels=24), x=(2, 3, 34, 34)),
 ]
+
+
+# ---- branch / merge containers, interpolation, stand-alone BN + activation ------------------------------------
+# name -> input shape. The blocks are built by `build_f4_block` from a namespace of constructors, so that the fixture generator
+# (the reference's classes) and the tests (pytorchcv_amd's) assemble literally the same structure.
+F4_CASES = {
+    "norm_activation": (2, 64, 9, 9),
+    "interp_bilinear_up2": (2, 32, 7, 9),
+    "interp_bilinear_noalign_size": (1, 16, 6, 7),
+    "interp_nearest_up2": (2, 24, 5, 6),
+    "interp_bilinear_down2": (1, 24, 12, 10),
+    "concurrent_cat": (2, 32, 10, 10),
+    "concurrent_cat_pool": (2, 32, 9, 11),
+    "concurrent_sum": (2, 32, 10, 10),
+    "seq_concurrent": (2, 16, 8, 8),
+    "channel_shuffle_g2": (2, 48, 6, 5),
+}
+
+
+def build_f4_block(name, ns):
+    """`ns`: object with Concurrent, SequentialConcurrent, NormActivation, InterpolationBlock, ChannelShuffle, conv1x1_block,
+    conv3x3_block, Sequential, MaxPool (3x3 / stride 1 / pad 1 factory)."""
+    if name == "norm_activation":
+        return ns.NormActivation(in_channels=64)
+    if name == "interp_bilinear_up2":
+        return ns.InterpolationBlock(scale_factor=2)
+    if name == "interp_bilinear_noalign_size":
+        return ns.InterpolationBlock(scale_factor=None, out_size=(13, 10), align_corners=False)
+    if name == "interp_nearest_up2":
+        return ns.InterpolationBlock(scale_factor=2, mode="nearest", align_corners=None)
+    if name == "interp_bilinear_down2":
+        return ns.InterpolationBlock(scale_factor=2, up=False)
+    if name == "concurrent_cat":
+        blk = ns.Concurrent()
+        blk.add_module("branch1", ns.conv1x1_block(in_channels=32, out_channels=16))
+        blk.add_module("branch2", ns.conv3x3_block(in_channels=32, out_channels=24))
+        b3 = ns.Sequential()
+        b3.add_module("conv1", ns.conv1x1_block(in_channels=32, out_channels=8))
+        b3.add_module("conv2", ns.conv3x3_block(in_channels=8, out_channels=32))
+        blk.add_module("branch3", b3)
+        return blk
+    if name == "concurrent_cat_pool":
+        blk = ns.Concurrent()
+        blk.add_module("branch1", ns.conv3x3_block(in_channels=32, out_channels=16))
+        b2 = ns.Sequential()
+        b2.add_module("pool", ns.MaxPool())
+        b2.add_module("conv", ns.conv1x1_block(in_channels=32, out_channels=8))
+        blk.add_module("branch2", b2)
+        blk.add_module("branch3", ns.MaxPool())
+        return blk
+    if name == "concurrent_sum":
+        blk = ns.Concurrent(merge_type="sum")
+        blk.add_module("branch1", ns.conv1x1_block(in_channels=32, out_channels=32))
+        blk.add_module("branch2", ns.conv3x3_block(in_channels=32, out_channels=32))
+        blk.add_module("branch3", ns.MaxPool())
+        return blk
+    if name == "seq_concurrent":
+        blk = ns.SequentialConcurrent()
+        blk.add_module("conv1", ns.conv3x3_block(in_channels=16, out_channels=16))
+        blk.add_module("conv2", ns.conv3x3_block(in_channels=16, out_channels=16))
+        return blk
+    if name == "channel_shuffle_g2":
+        return ns.ChannelShuffle(channels=48, groups=2)
+    raise KeyError(name)

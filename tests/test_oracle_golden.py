@@ -85,3 +85,17 @@ def test_quantisation_matched_mode_is_close_to_fp32_and_idempotent():
         assert float((yq - y32).abs().max()) <= tol
         dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[qd]
         assert torch.equal(yq, yq.to(dt).float())       # stored values are representable in the 16-bit type
+
+
+@pytest.mark.parametrize("name", sorted(util.F4_CASES))
+def test_rank4_block_oracle_matches_reference_golden(name):
+    """Concurrent / SequentialConcurrent / NormActivation / InterpolationBlock / ChannelShuffle: the oracle's
+    restatement against the outputs of the reference's own classes (tests/golden/make_golden_f4.py), and the pytorchcv_amd
+    module tree registers the same state_dict keys and shapes."""
+    from oracle import refblocks
+    sd, x, g = util.f4_golden(name)
+    y = refblocks.f4_block_forward(name, sd, x)
+    assert y.shape == g.shape
+    assert float((y - g).abs().max()) <= 1e-5
+    blk = util.build_f4(name)
+    assert {k: tuple(v.shape) for k, v in blk.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 
 from pytorchcv_amd.synth import synth_state_dict, synth_input, hash_normal  # noqa: E402
-from cases import BLOCK_CASES, MODELS  # noqa: E402,F401
+from cases import BLOCK_CASES, MODELS, F4_CASES, build_f4_block  # noqa: E402,F401
 
 import contextlib  # noqa: E402
 
@@ -134,3 +134,33 @@ def digest(t: torch.Tensor, sample=64):
     idx = torch.linspace(0, f.numel() - 1, sample).long()
     return dict(shape=list(t.shape), sum=float(f.sum()), sumsq=float((f * f).sum()),
                 samples=[float(v) for v in t.flatten()[idx].float()])
+
+
+_f4 = None
+
+
+def f4_golden(name):
+    """(state dict, input, golden output of the imported reference) of a rank-4 block case (tests/golden/make_golden_f4.py)."""
+    global _f4
+    if _f4 is None:
+        with open(os.path.join(GOLDEN, "blocks_f4.json")) as f:
+            _f4 = (np.load(os.path.join(GOLDEN, "blocks_f4.npz")), json.load(f))
+    npz, meta = _f4
+    m = meta[name]
+    sd = synth_state_dict(template_from_manifest(m["manifest"]), seed=m["weight_seed"]) if m["manifest"] else {}
+    x = synth_input(*F4_CASES[name], seed=m["input_seed"])
+    return sd, x, torch.from_numpy(npz[name])
+
+
+def build_f4(name):
+    """The pytorchcv_amd counterpart of a rank-4 block case."""
+    import types
+    import torch.nn as nn
+    from pytorchcv_amd.models.common import arch, tutti, conv
+    from pytorchcv_amd.models._tail import MaxPool2dNHWC
+    ns = types.SimpleNamespace(Concurrent=arch.Concurrent, SequentialConcurrent=arch.SequentialConcurrent,
+                               NormActivation=tutti.NormActivation, InterpolationBlock=tutti.InterpolationBlock,
+                               ChannelShuffle=tutti.ChannelShuffle, conv1x1_block=conv.conv1x1_block,
+                               conv3x3_block=conv.conv3x3_block, Sequential=nn.Sequential,
+                               MaxPool=lambda: MaxPool2dNHWC(kernel_size=3, stride=1, padding=1))
+    return build_f4_block(name, ns).eval()
