@@ -63,9 +63,9 @@ class InterpolationBlock(nn.Module):
             type(self).__name__, self.scale_factor, self.out_size, self.mode, self.align_corners, self.up)
 
 
-def channel_shuffle(x, groups):
+def channel_shuffle(x, groups, module=None):
     """Channel shuffle of ShuffleNet: channels viewed as [groups, C / groups] and transposed. On the hot path for groups == 2
-    (the interleave of the two halves, pcv_channel_interleave2)."""
+    (the interleave of the two halves, pcv_channel_interleave2). `module`: whose compute dtype an NCHW input is converted to."""
     def run(a):
         if groups != 2 or a.C % 2:
             raise NotImplementedError("channel_shuffle with {} groups is not on the MI355X path (groups = 2 is)".format(groups))
@@ -74,8 +74,7 @@ def channel_shuffle(x, groups):
         return engine.cat_shuffle2(a, second, half)
     if isinstance(x, engine.NHWC):
         return run(x)
-    holder = nn.Module()
-    return engine.boundary(holder, x, run)
+    return engine.boundary(module if module is not None else nn.Module(), x, run)
 
 
 class ChannelShuffle(nn.Module):
@@ -86,7 +85,7 @@ class ChannelShuffle(nn.Module):
         self.groups = groups
 
     def forward(self, x):
-        return channel_shuffle(x, self.groups)
+        return channel_shuffle(x, self.groups, module=self)
 
     def __repr__(self):
         return "{}(groups={})".format(type(self).__name__, self.groups)
