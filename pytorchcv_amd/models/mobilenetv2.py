@@ -3,13 +3,13 @@
     depthwise 3x3 (direct HBM-bound kernel), project 1x1 with the skip add in its epilogue; bias-free 1x1-conv classifier.
 """
 
-__all__ = ['MobileNetV2', 'mobilenetv2_w1', 'mobilenetv2_w3d4', 'mobilenetv2_wd2', 'mobilenetv2_wd4', 'LinearBottleneck',
-           'get_mobilenetv2']
+__all__ = ['MobileNetV2', 'LinearBottleneck', 'get_mobilenetv2']
 
 import torch.nn as nn
 from .common.activ import lambda_relu6
 from .common.conv import conv1x1, conv1x1_block, conv3x3_block, dwconv3x3_block, mbconv_chain
-from ._tail import AvgPool2dNHWC, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
+from ._build import ClassifierNet, add_stages, register_variants, scale_widths
+from ._tail import maybe_load_pretrained, DEFAULT_ROOT
 from .. import engine
 
 
@@ -37,33 +37,20 @@ class LinearBottleneck(nn.Module):
         return engine.boundary(self, x, self._run)
 
 
-class MobileNetV2(nn.Module):
+class MobileNetV2(ClassifierNet):
     def __init__(self, channels, init_block_channels, final_block_channels, remove_exp_conv, in_channels=3,
                  in_size=(224, 224), num_classes=1000):
-        super(MobileNetV2, self).__init__()
-        self.in_size = in_size
-        self.num_classes = num_classes
-        activation = lambda_relu6()
-        self.features = nn.Sequential()
+        super(MobileNetV2, self).__init__(in_size, num_classes)
+        act = lambda_relu6()
         self.features.add_module("init_block", conv3x3_block(in_channels=in_channels, out_channels=init_block_channels,
-                                                             stride=2, activation=activation))
-        in_channels = init_block_channels
-        for i, channels_per_stage in enumerate(channels):
-            stage = nn.Sequential()
-            for j, out_channels in enumerate(channels_per_stage):
-                stride = 2 if (j == 0) and (i != 0) else 1
-                expansion = (i != 0) or (j != 0)
-                stage.add_module("unit{}".format(j + 1), LinearBottleneck(
-                    in_channels=in_channels, out_channels=out_channels, stride=stride, expansion=expansion,
-                    remove_exp_conv=remove_exp_conv, activation=activation))
-                in_channels = out_channels
-            self.features.add_module("stage{}".format(i + 1), stage)
-        self.features.add_module("final_block", conv1x1_block(in_channels=in_channels, out_channels=final_block_channels,
-                                                              activation=activation))
-        in_channels = final_block_channels
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
-        self.output = conv1x1(in_channels=in_channels, out_channels=num_classes, bias=False)
-        init_conv_params(self)
+                                                             stride=2, activation=act))
+        width = add_stages(
+            self.features, init_block_channels, channels,
+            make_unit=lambda cin, cout, stride, i, j: LinearBottleneck(
+                in_channels=cin, out_channels=cout, stride=stride, expansion=(i, j) != (0, 0),   # the very first unit does not expand
+                remove_exp_conv=remove_exp_conv, activation=act))
+        self.features.add_module("final_block", conv1x1_block(in_channels=width, out_channels=final_block_channels, activation=act))
+        self.finish(final_block_channels, head=conv1x1(in_channels=final_block_channels, out_channels=num_classes, bias=False))
 
     def _head(self, a):
         if a.H != 1 or a.W != 1:
@@ -71,41 +58,25 @@ class MobileNetV2(nn.Module):
         y = self.output(a, out_fp32=True)
         return y.t.view(y.N, -1)
 
-    def forward(self, x):
-        return run_net(self, x, self._head)
+
+# (width, units, opens a new stage = stride 2): seven groups of inverted-residual units in five stages
+_GROUPS = ((16, 1, False), (24, 2, True), (32, 3, True), (64, 4, True), (96, 3, False), (160, 3, True), (320, 1, False))
+_STEM, _FINAL = 32, 1280
 
 
 def get_mobilenetv2(width_scale, remove_exp_conv=False, model_name=None, pretrained=False, root=DEFAULT_ROOT, **kwargs):
-    """Channel plan of reference mobilenetv2.py:183-203: a stage boundary wherever `downsample` is set."""
-    init_block_channels, final_block_channels = 32, 1280
-    plan = [(16, 1, 0), (24, 2, 1), (32, 3, 1), (64, 4, 1), (96, 3, 0), (160, 3, 1), (320, 1, 0)]
-    channels = [[]]
-    for width, count, downsample in plan:
-        if downsample:
-            channels.append([width] * count)
-        else:
-            channels[-1] = channels[-1] + [width] * count
-    if width_scale != 1.0:
-        channels = [[int(c * width_scale) for c in ci] for ci in channels]
-        init_block_channels = int(init_block_channels * width_scale)
-        if width_scale > 1.0:
-            final_block_channels = int(final_block_channels * width_scale)
-    net = MobileNetV2(channels=channels, init_block_channels=init_block_channels, final_block_channels=final_block_channels,
+    stages = []
+    for width, units, new_stage in _GROUPS:
+        if new_stage or not stages:
+            stages.append([])
+        stages[-1] += [width] * units
+    net = MobileNetV2(channels=scale_widths(stages, width_scale),
+                      init_block_channels=_STEM if width_scale == 1.0 else int(_STEM * width_scale),
+                      final_block_channels=int(_FINAL * width_scale) if width_scale > 1.0 else _FINAL,   # never narrower than 1280
                       remove_exp_conv=remove_exp_conv, **kwargs)
     return maybe_load_pretrained(net, model_name, pretrained, root)
 
 
-def mobilenetv2_w1(**kwargs):
-    return get_mobilenetv2(width_scale=1.0, model_name="mobilenetv2_w1", **kwargs)
-
-
-def mobilenetv2_w3d4(**kwargs):
-    return get_mobilenetv2(width_scale=0.75, model_name="mobilenetv2_w3d4", **kwargs)
-
-
-def mobilenetv2_wd2(**kwargs):
-    return get_mobilenetv2(width_scale=0.5, model_name="mobilenetv2_wd2", **kwargs)
-
-
-def mobilenetv2_wd4(**kwargs):
-    return get_mobilenetv2(width_scale=0.25, model_name="mobilenetv2_wd4", **kwargs)
+register_variants(__name__, get_mobilenetv2, {
+    "mobilenetv2_w1": dict(width_scale=1.0), "mobilenetv2_w3d4": dict(width_scale=0.75),
+    "mobilenetv2_wd2": dict(width_scale=0.5), "mobilenetv2_wd4": dict(width_scale=0.25)})

@@ -3,14 +3,14 @@
     carries the stride) runs as block-diagonal implicit GEMM over 32-channel group blocks.
 """
 
-__all__ = ['ResNeXt', 'resnext14_16x4d', 'resnext14_32x2d', 'resnext14_32x4d', 'resnext26_32x4d', 'resnext50_32x4d',
-           'resnext101_32x4d', 'resnext101_64x4d', 'ResNeXtBottleneck', 'ResNeXtUnit', 'get_resnext']
+__all__ = ['ResNeXt', 'ResNeXtBottleneck', 'ResNeXtUnit', 'get_resnext']
 
 import math
 import torch.nn as nn
 from .common.conv import conv1x1_block, conv3x3_block, conv_block_pair
 from .resnet import ResInitBlock, ResStage
-from ._tail import AvgPool2dNHWC, LinearHead, run_net, maybe_load_pretrained, init_conv_params, DEFAULT_ROOT
+from ._build import ClassifierNet, add_stages, register_variants, stage_table
+from ._tail import maybe_load_pretrained, DEFAULT_ROOT
 from .. import engine
 
 
@@ -61,67 +61,36 @@ class ResNeXtUnit(nn.Module):
         return engine.boundary(self, x, self._run)
 
 
-class ResNeXt(nn.Module):
+class ResNeXt(ClassifierNet):
     def __init__(self, channels, init_block_channels, cardinality, bottleneck_width, in_channels=3, in_size=(224, 224),
                  num_classes=1000):
-        super(ResNeXt, self).__init__()
-        self.in_size = in_size
-        self.num_classes = num_classes
-        self.features = nn.Sequential()
+        super(ResNeXt, self).__init__(in_size, num_classes)
         self.features.add_module("init_block", ResInitBlock(in_channels=in_channels, out_channels=init_block_channels))
-        in_channels = init_block_channels
-        for i, channels_per_stage in enumerate(channels):
-            stage = ResStage()
-            for j, out_channels in enumerate(channels_per_stage):
-                stride = 2 if (j == 0) and (i != 0) else 1
-                stage.add_module("unit{}".format(j + 1), ResNeXtUnit(in_channels=in_channels, out_channels=out_channels,
-                                                                     stride=stride, cardinality=cardinality,
-                                                                     bottleneck_width=bottleneck_width))
-                in_channels = out_channels
-            self.features.add_module("stage{}".format(i + 1), stage)
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
-        self.output = LinearHead(in_features=in_channels, out_features=num_classes)
-        init_conv_params(self)
+        width = add_stages(
+            self.features, init_block_channels, channels, container=ResStage,
+            make_unit=lambda cin, cout, stride, i, j: ResNeXtUnit(in_channels=cin, out_channels=cout, stride=stride,
+                                                                  cardinality=cardinality, bottleneck_width=bottleneck_width))
+        self.finish(width)
 
-    def forward(self, x):
-        return run_net(self, x, self.output)
+
+_DEPTHS = {14: (1, 1, 1, 1), 26: (2, 2, 2, 2), 38: (3, 3, 3, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}     # bottleneck units per stage
 
 
 def get_resnext(blocks, cardinality, bottleneck_width, model_name=None, pretrained=False, root=DEFAULT_ROOT, **kwargs):
-    table = {14: [1, 1, 1, 1], 26: [2, 2, 2, 2], 38: [3, 3, 3, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}
-    if blocks not in table:
+    if blocks not in _DEPTHS:
         raise ValueError("Unsupported ResNeXt with number of blocks: {}".format(blocks))
-    layers = table[blocks]
-    assert (sum(layers) * 3 + 2 == blocks)
-    channels = [[w] * n for (w, n) in zip([256, 512, 1024, 2048], layers)]
-    net = ResNeXt(channels=channels, init_block_channels=64, cardinality=cardinality, bottleneck_width=bottleneck_width,
-                  **kwargs)
+    net = ResNeXt(channels=stage_table((256, 512, 1024, 2048), _DEPTHS[blocks]), init_block_channels=64,
+                  cardinality=cardinality, bottleneck_width=bottleneck_width, **kwargs)
     return maybe_load_pretrained(net, model_name, pretrained, root)
 
 
-def resnext14_16x4d(**kwargs):
-    return get_resnext(blocks=14, cardinality=16, bottleneck_width=4, model_name="resnext14_16x4d", **kwargs)
+def _variant(name):
+    """`resnext<blocks>_<cardinality>x<width>d` -> the three numbers."""
+    depth, shape = name[len("resnext"):].split("_")
+    card, width = shape[:-1].split("x")
+    return dict(blocks=int(depth), cardinality=int(card), bottleneck_width=int(width))
 
 
-def resnext14_32x2d(**kwargs):
-    return get_resnext(blocks=14, cardinality=32, bottleneck_width=2, model_name="resnext14_32x2d", **kwargs)
-
-
-def resnext14_32x4d(**kwargs):
-    return get_resnext(blocks=14, cardinality=32, bottleneck_width=4, model_name="resnext14_32x4d", **kwargs)
-
-
-def resnext26_32x4d(**kwargs):
-    return get_resnext(blocks=26, cardinality=32, bottleneck_width=4, model_name="resnext26_32x4d", **kwargs)
-
-
-def resnext50_32x4d(**kwargs):
-    return get_resnext(blocks=50, cardinality=32, bottleneck_width=4, model_name="resnext50_32x4d", **kwargs)
-
-
-def resnext101_32x4d(**kwargs):
-    return get_resnext(blocks=101, cardinality=32, bottleneck_width=4, model_name="resnext101_32x4d", **kwargs)
-
-
-def resnext101_64x4d(**kwargs):
-    return get_resnext(blocks=101, cardinality=64, bottleneck_width=4, model_name="resnext101_64x4d", **kwargs)
+register_variants(__name__, get_resnext, {n: _variant(n) for n in (
+    "resnext14_16x4d", "resnext14_32x2d", "resnext14_32x4d", "resnext26_32x4d", "resnext50_32x4d", "resnext101_32x4d",
+    "resnext101_64x4d")})
