@@ -17,6 +17,7 @@
 #include "mbconv.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
+#include "head_gemm.hpp"
 
 
 IGEMM_INSTANCES(IGEMM_DECLARE, PCV_BF16)
@@ -32,6 +33,7 @@ struct pcv_ctx {
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
@@ -632,6 +634,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
+    else if (k == "head") ctx->use_head = value;
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
     else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;
@@ -922,6 +925,24 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         nb = (nb + 7) / 8 * 8;
         void* args[] = {&q};
         HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));
+        return PCV_OK;
+    }
+
+    // ---- dense layer on a 1x1 map, fp32 (classifier): many small blocks instead of a handful of 128x128 tiles ------------------
+    if (ctx->use_head && d->dtype == PCV_F32 && d->out_dtype == PCV_F32 && d->kh == 1 && d->kw == 1 && d->H == 1 && d->W == 1 &&
+        P.Ho == 1 && P.Wo == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 && !gate &&
+        !d->has_residual && d->post_act == PCV_ACT_NONE && d->Cin % 16 == 0) {
+        const int ypitchh = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+        if (ypitchh < d->Cout) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout");
+        HeadParams q;
+        q.x = static_cast<const float*>(x); q.w = reinterpret_cast<const float*>(static_cast<const char*>(packed) + P.ktab_bytes);
+        q.scale = scale; q.shift = shift; q.y = static_cast<float*>(y);
+        q.M = d->N; q.K = d->Cin; q.Kpad = P.Kpad; q.Cout = d->Cout; q.Xpitch = cpitch; q.Ypitch = ypitchh; q.act = d->act;
+        const unsigned gx = (unsigned)(P.wrows / 32);
+        const bool wide = (long long)gx * ((d->N + 31) / 32) >= 2ll * ctx->num_cu;      // enough 32-image blocks for two per CU
+        if (wide) hipLaunchKernelGGL(head_gemm_f32_kernel<32>, dim3(gx, (unsigned)((d->N + 31) / 32)), dim3(256), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(head_gemm_f32_kernel<16>, dim3(gx, (unsigned)((d->N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
 

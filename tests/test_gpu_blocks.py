@@ -492,3 +492,37 @@ def test_nan_in_is_nan_out(act, dtype, cuda_device):
         else:
             want[0, 3, 3:6, 4:7] = True             # depthwise: channel 3 only
         assert torch.equal(nan, want), "{}: {} NaN outputs, expected {}".format(ctor.__name__, int(nan.sum()), int(want.sum()))
+
+
+# the fp32 classifier kernel (csrc/head_gemm.hpp): nn.Linear / 1x1 `output` convolution on the pooled [N, 1, 1, K] map
+_HEAD_SHAPES = [(40, 2048, 1000, True), (256, 512, 1000, True), (7, 1280, 1000, False), (520, 1024, 1000, True), (33, 48, 10, True),
+                (3, 2064, 24, False)]
+
+
+@pytest.mark.parametrize("shape", _HEAD_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _HEAD_SHAPES])
+def test_fp32_head_gemm_vs_generic_and_fp64(shape, cuda_device):
+    """Logits from the dedicated head kernel agree with the generic implicit-GEMM tiles (same exact-fp32 products, another
+    summation order: 2e-5 relative to the row's magnitude), with an fp64 reference, and an image's logits depend neither on its
+    position in the batch nor on the batch size (bit-equal when the same images are run 5 at a time)."""
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1
+    N, K, J, bias = shape
+    conv = conv1x1(in_channels=K, out_channels=J, bias=bias).eval()
+    sd = util.synth_state_dict(conv.state_dict(), seed=5)
+    conv.load_state_dict(sd)
+    conv = conv.to(cuda_device)
+    x = util.synth_input(N, K, 1, 1, seed=6)
+    xd = x.to(cuda_device).permute(0, 2, 3, 1).contiguous()
+
+    def run(xs, **sw):
+        with torch.no_grad(), util.tuning(**sw):
+            y = conv(engine.NHWC(xs, xs.shape[0], 1, 1, K), out_fp32=True)
+        assert y.t.dtype == torch.float32
+        return y.t.view(xs.shape[0], -1)[:, :J].cpu()
+    y_head, y_gen = run(xd, head=1), run(xd, head=0)
+    ref = x.view(N, K).double() @ sd["weight"].view(J, K).double().t() + (sd["bias"].double() if bias else 0.0)
+    scale = ref.abs().max().item() + 1.0
+    assert float((y_head.double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((y_head - y_gen).abs().max()) <= 2e-5 * scale
+    pieces = [run(xd[i:i + 5].contiguous(), head=1) for i in range(0, N, 5)]
+    assert torch.equal(torch.cat(pieces), y_head)
