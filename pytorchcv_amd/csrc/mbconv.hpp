@@ -11,8 +11,11 @@
 //                                          tile's x is fetched while this one computes); pixels outside the image are
 //                                          forced to 0 (the depthwise pads the EXPANDED map).
 //       without an expand convolution the chunk of x itself is the DMA target.
-//   S2  D[chunk][TH x 16 pixels]         = act(BN(depthwise 3x3 of E))            VALU: a thread owns 8 channels of one
-//                                          output column and 1-2 rows, its input window is unpacked once
+//   S2  D[chunk][TH x 16 pixels]         = act(BN(depthwise 3x3 of E))            MFMA with block-diagonal weights: one
+//                                          16x16x32 step = 2 taps x 16 channels (K) -> 16 channels x 16 pixels of one output
+//                                          row, 5 steps for the 9 taps; a lane's B chunk is 8 channels of the pixel shifted by
+//                                          its tap, read straight from the E tile (gconv3x3.hpp's scheme at group size 1). The
+//                                          VALU version of this stage (unpack + v_pk_fma_f32 per tap) was 33-47 % of the kernel.
 //   S3  acc[Cout][TH x 16]              += W_proj[:, chunk] . D                   MFMA
 //
 // then BN (+ residual) and 16-byte NHWC stores. E, D and the weight slabs are rows of 64 bytes (32 channels) with the
@@ -74,7 +77,6 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
     constexpr int NPT = (NIP + 15) / 16;                // 16-pixel MFMA blocks over the input tile: 12 / 19
     constexpr int MAXPT = (NPT + 3) / 4;                // per wave
     constexpr int NJ = TH / 4;                          // output pixel blocks per wave in the project GEMM
-    constexpr int NIT = TH / 4;                         // vertically adjacent depthwise outputs per thread
     constexpr int ESZ = NPT * 16 * 64;
     typedef typename Mma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -163,13 +165,33 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
         for (int ks = 0; ks < p.ka; ++ks) dma_tile(t, Xs + (buf * p.ka + ks) * ESZ, 32 * ks);
     };
 
-    // ---- depthwise work of this thread: 8-channel slot q of output column ocol, NIT vertically adjacent output rows
-    //      (stride 1: rows 2g, 2g+1 share a 4-row input window; stride 2: one row). tid = ((g * 16) + ocol) * 4 + q.
-    const int q = tid & 3;
-    const int ocol = (tid >> 2) & 15;
-    const int orow0 = (tid >> 6) * NIT;
-    constexpr int WROWS = (NIT - 1) * S + 3;            // input rows of the window
-    const int dbase = (orow0 * S) * IW + ocol * S;
+    // ---- depthwise work of this wave: 16-channel half `dg` of every chunk, NB output rows (16 pixels each) ---------------------
+    // A (weights, rows = channels): lane (row fr, k quarter fq) holds k = 8 fq .. 8 fq + 7 = tap (fq >> 1) of the pair, channels
+    // 8 (fq & 1) .. + 7 of the half: non-zero only on the diagonal, i.e. element fr & 7 when (fr >> 3) == (fq & 1).
+    // B (E tile, columns = pixels of one output row): lane (column fr, fq) reads the same 8 channels of the pixel under its tap.
+    constexpr int NB = TH / 2;
+    const int dg = wave & 1;
+    const int drow0 = (wave >> 1) * NB;
+    uint32_t boff[NB][5], doff[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int tap = min(2 * j + (fq >> 1), 8);                   // tap 9 does not exist: its weights are zero
+            const int ip = ((drow0 + u) * S + tap / 3) * IW + fr * S + tap % 3;
+            boff[u][j] = (uint32_t)(ip * 64 + (((2 * dg + (fq & 1)) ^ mb_swz(ip)) << 4));
+        }
+        const int op = (drow0 + u) * 16 + fr;                            // accumulator rows 4 fq .. 4 fq + 3 = channels 16 dg + 4 fq ..
+        doff[u] = (uint32_t)(op * 64 + (((2 * dg + (fq >> 1)) ^ mb_swz(op)) << 4) + 8 * (fq & 1));
+    }
+    uint32_t am[4], am4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        am[i] = ((fr >> 3) == (fq & 1) && i == ((fr & 7) >> 1)) ? 0xFFFFFFFFu : 0u;
+        am4[i] = (fq >> 1) ? 0u : am[i];
+    }
+    const int a_sh = (fr & 1) * 16;
+    const int a_woff = ((fq >> 1) * CmidP + 16 * dg + fr) * 2;          // + (2 j * CmidP + 32 c) * 2
 
     if constexpr (EXPAND) dma_x(tile, 0);
     int xbuf = 0;
@@ -259,70 +281,37 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
                 if (c + 1 < p.nChunks) dma_tile(tile, Es + ((c + 1) & 1) * ESZ, 32 * (c + 1));   // buffer last read in S2(c-1)
             }
 
-            // ---- S2: depthwise 3x3 over the E tile -> D --------------------------------------------------------------------------
+            // ---- S2: depthwise 3x3 over the E tile -> D (block-diagonal MFMA) -----------------------------------------------------
             {
-                f32x2 a[NIT][4];
+                frag af[5];
 #pragma unroll
-                for (int k = 0; k < NIT; ++k)
+                for (int j = 0; j < 5; ++j) {
+                    // (the last pair's second tap reads the 16 bits behind the table - still this block's LDS - and is masked off)
+                    const uint32_t w16 = *reinterpret_cast<const uint16_t*>(Wds + a_woff + (2 * j * CmidP + 32 * c) * 2);
+                    const uint32_t val = w16 << a_sh;
+                    u32x4 a4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a[k][e] = (f32x2){0.f, 0.f};
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    f32x2 wv[3][4];                              // this column's three taps, unpacked once
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const u32x4 wr = *reinterpret_cast<const u32x4*>(Wds + ((dy * 3 + dx) * CmidP + 32 * c + 8 * q) * 2);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float w0, w1;
-                            unpack2<DT>(wr[e], w0, w1);
-                            wv[dy][e] = (f32x2){w0, w1};
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < WROWS; ++r) {
-                        const int ip = dbase + r * IW + dx;
-                        const u32x4 ev = *reinterpret_cast<const u32x4*>(Ec + ip * 64 + ((q ^ mb_swz(ip)) << 4));
-                        f32x2 xv[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x0, x1;
-                            unpack2<DT>(ev[e], x0, x1);
-                            xv[e] = (f32x2){x0, x1};
-                        }
-#pragma unroll
-                        for (int k = 0; k < NIT; ++k) {
-                            const int dy = r - k * S;            // input row r feeds output row k through tap dy
-                            if (dy >= 0 && dy < 3) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) a[k][e] += xv[e] * wv[dy][e];
-                            }
-                        }
-                    }
+                    for (int i = 0; i < 4; ++i) a4[i] = val & (j < 4 ? am[i] : am4[i]);
+                    af[j] = __builtin_bit_cast(frag, a4);
                 }
-                const f32x4 sd0 = *reinterpret_cast<const f32x4*>(BNs + 2 * CmidP + 32 * c + 8 * q);
-                const f32x4 sd1 = *reinterpret_cast<const f32x4*>(BNs + 2 * CmidP + 32 * c + 8 * q + 4);
-                const f32x4 hd0 = *reinterpret_cast<const f32x4*>(BNs + 3 * CmidP + 32 * c + 8 * q);
-                const f32x4 hd1 = *reinterpret_cast<const f32x4*>(BNs + 3 * CmidP + 32 * c + 8 * q + 4);
+                const f32x4 sd = *reinterpret_cast<const f32x4*>(BNs + 2 * CmidP + 32 * c + 16 * dg + 4 * fq);
+                const f32x4 hd = *reinterpret_cast<const f32x4*>(BNs + 3 * CmidP + 32 * c + 16 * dg + 4 * fq);
 #pragma unroll
-                for (int k = 0; k < NIT; ++k) {
-                    float v[8];
+                for (int u = 0; u < NB; ++u) {
+                    f32x4 da = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] = a[k][e][0];
-                        v[2 * e + 1] = a[k][e][1];
+                    for (int j = 0; j < 5; ++j) {
+                        const frag b = *reinterpret_cast<const frag*>(Ec + boff[u][j]);
+                        da = Mma<DT>::run(af[j], b, da);
                     }
+                    float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = v[e] * sd0[e] + hd0[e];
-                        v[4 + e] = v[4 + e] * sd1[e] + hd1[e];
-                    }
-                    apply_act8(v, act_d);
-                    u32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-                    const int op = (orow0 + k) * 16 + ocol;
-                    *reinterpret_cast<u32x4*>(Ds + op * 64 + ((q ^ mb_swz(op)) << 4)) = o;
+                    for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
+                    apply_actn<4>(v, act_d);
+                    u32x2 o;
+                    o[0] = pack2<DT>(v[0], v[1]);
+                    o[1] = pack2<DT>(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(Ds + doff[u]) = o;
                 }
             }
             __syncthreads();

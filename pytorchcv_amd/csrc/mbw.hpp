@@ -1,0 +1,304 @@
+// mbw.hpp - the fused inverted-residual unit (mbconv.hpp: 1x1 expand + BN + act -> depthwise 3x3 + BN + act -> 1x1 project + BN
+// (+ skip); reference LinearBottleneck.forward, mobilenetv2.py:62-71) with WAVE-PRIVATE tiles: no block barrier after the weights
+// are in LDS.
+//
+// mbconv.hpp's block owns a TH x 16 output tile and its four waves meet at two barriers per 32-channel chunk; with 5 pixel blocks
+// of expand work per wave between barriers the unit ran at 7-8 K cycles per chunk for ~1.5 K cycles of instructions (16 -> 96 ->
+// 24 at 112x112: 559 us against a 70 us HBM floor). Here every wave owns an R x 16 output tile (R = 4 rows at stride 1, 2 at
+// stride 2) and keeps its own E / D chunk tiles in LDS, so its three stages are one straight instruction stream (LDS operations
+// of a wave execute in order: no barrier, no explicit wait), and eight such waves per CU hide each other's latencies. The price
+// is the expand work of the halo rows that neighbouring waves no longer share (1.75 / 5.2 expanded pixels per output at stride
+// 1 / 2 instead of 1.4 / 4.6).
+//
+//   x   the window's pixels go global -> registers as MFMA B fragments (lane = pixel l % 16, channels 8 (l / 16) .. + 7; padding and
+//       channel tails = out-of-range buffer offsets = zeros), prefetched one tile ahead. No LDS staging: Cin <= 32 is one K step.
+//   S1  E[window pixel][32 ch] = act(BN(W_exp[chunk] . x)); outside the image forced to 0 (the depthwise pads the EXPANDED map)
+//   S2  D[R x 16 pixels][32 ch] = act(BN(depthwise 3x3 of E)) as block-diagonal MFMAs (2 taps x 16 channels per K = 32 step, 5 steps)
+//   S3  acc[Cout][R x 16] += W_proj[:, chunk] . D
+//   then BN (+ residual) and 16-byte NHWC stores.
+// All LDS rows (weights, E, D) are 64 bytes of payload on an 80-byte pitch: 16 lanes reading the same 16-byte slot of 16
+// consecutive rows touch every bank once (20 i mod 64 walks all multiples of 4), so addresses stay affine - tap, row and channel
+// half are immediate offsets - and nothing is swizzled.
+#pragma once
+#include "pcv_common.hpp"
+#include "igemm_conv.hpp"     // Mma<DT>
+#include "mbconv.hpp"         // MbParams
+
+struct MbwLds {
+    int wexp, wproj, wdw, bn, wave0, per_wave, total;
+};
+static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves) {
+    const int npt = stride == 1 ? 7 : 11, rows = stride == 1 ? 4 : 2;
+    MbwLds L;
+    int o = 0;
+    L.wexp = o; o += nChunks * 32 * 80;                           // [chunk][32 rows]
+    L.wproj = o; o += nChunks * nrt * 16 * 80;                    // [chunk][nrt * 16 rows]
+    L.wdw = o; o += (10 * nChunks * 32 * 2 + 15) & ~15;           // [10][CmidP] 16-bit: tap 9 = zeros (second half of the last tap pair)
+    L.bn = o; o += 4 * nChunks * 32 * 4;                          // scale_e, shift_e, scale_d, shift_d
+    L.wave0 = o;
+    L.per_wave = (npt * 16 + rows * 16) * 80;                     // E tile + D tile
+    o += nWaves * L.per_wave;
+    L.total = o;
+    return L;
+}
+
+// S: stride; NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64). Cin <= 32. blockDim.x = 64 * waves.
+template <int DT, int S, int NRT>
+__global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int R = S == 1 ? 4 : 2;                   // output rows per wave tile (x 16 columns)
+    constexpr int IH = (R - 1) * S + 3, IW = 15 * S + 3;
+    constexpr int NIP = IH * IW;                        // window pixels: 108 / 165
+    constexpr int NPT = (NIP + 15) / 16;                // 7 / 11
+    constexpr int PITCH = 80;
+    typedef typename Mma<DT>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nWaves = blockDim.x >> 6;
+    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    char* const Wes = smem + L.wexp;
+    char* const Wps = smem + L.wproj;
+    char* const Wds = smem + L.wdw;
+    float* const BNs = reinterpret_cast<float*>(smem + L.bn);
+    char* const Es = smem + L.wave0 + wave * L.per_wave;
+    char* const Ds = Es + NPT * 16 * PITCH;
+    const int CmidP = p.nChunks * 32;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res ? p.y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wersrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_exp), 0, p.wexp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wdrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_dw), 0, p.wdw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wprsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_proj), 0, p.wproj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sprsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale_p), 0, p.Cout * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hprsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift_p), 0, p.Cout * 4, 0x00020000);
+
+    // ---- the unit's weights -> LDS, once per block (rows beyond the packed matrices / channels beyond Cmid read as zeros) --------
+    for (int i = tid; i < p.nChunks * 32 * 4; i += blockDim.x) {
+        const int slot = i & 3, row = i >> 2;                                      // row = 32 c + r: packed row order = MFMA order
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wersrc, (uint32_t)((row * p.Kpad1 + 8 * slot) * 2), 0, 0);
+        *reinterpret_cast<u32x4*>(Wes + row * PITCH + slot * 16) = v;
+    }
+    for (int i = tid; i < p.nChunks * NRT * 16 * 4; i += blockDim.x) {
+        const int slot = i & 3, row = (i >> 2) % (NRT * 16), c = (i >> 2) / (NRT * 16);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wprsrc, (uint32_t)((row * p.Kpad2 + 32 * c + 8 * slot) * 2), 0, 0);
+        *reinterpret_cast<u32x4*>(Wps + (c * NRT * 16 + row) * PITCH + slot * 16) = v;
+    }
+    for (int i = tid; i < 10 * CmidP / 8; i += blockDim.x) {
+        const int t = i / (CmidP / 8), ch = (i - t * (CmidP / 8)) * 8;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wdrsrc, (t < 9 && ch < p.Cmid) ? (uint32_t)((t * p.Cmid + ch) * 2) : 0x80000000u, 0, 0);
+        *reinterpret_cast<u32x4*>(Wds + (t * CmidP + ch) * 2) = v;
+    }
+    for (int i = tid; i < 4 * CmidP; i += blockDim.x) {
+        const int which = i / CmidP, ch = i - which * CmidP;
+        const float* src = which == 0 ? p.scale_e : which == 1 ? p.shift_e : which == 2 ? p.scale_d : p.shift_d;
+        BNs[i] = (ch < p.Cmid && src != nullptr) ? src[ch] : 0.f;
+    }
+    __syncthreads();                                                               // the only barrier of the kernel
+
+    const ActClamp act_e = make_act(p.act_e), act_d = make_act(p.act_d), act_p = make_act(p.act_p), post = make_act(p.post);
+
+    // ---- lane constants ----------------------------------------------------------------------------------------------------------
+    // window pixel 16 m + fr of this lane: (row << 8) | column; pixels past the window get row 255 (never inside an image: H <= 250)
+    uint32_t prc[NPT];
+#pragma unroll
+    for (int m = 0; m < NPT; ++m) {
+        const int ip = 16 * m + fr;
+        prc[m] = ip < NIP ? (uint32_t)(((ip / IW) << 8) | (ip % IW)) : 0xFF00u;
+    }
+    // S2: A (weights, rows = channels) lane (row fr, k quarter fq) holds tap (fq >> 1) of the pair, channels 8 (fq & 1) .. + 7 of the
+    // 16-channel half: non-zero only on the diagonal, element fr & 7 when (fr >> 3) == (fq & 1). B (E tile, columns = the 16 pixels
+    // of one output row): lane (column fr, fq) reads the same 8 channels of the pixel under its tap.
+    uint32_t am[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) am[i] = ((fr >> 3) == (fq & 1) && i == ((fr & 7) >> 1)) ? 0xFFFFFFFFu : 0u;
+    const int a_sh = (fr & 1) * 16;
+    const char* const a_w = Wds + ((fq >> 1) * CmidP + fr) * 2;                    // + (2 j CmidP + 32 c + 16 g) * 2
+    uint32_t boff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int tap = min(2 * j + (fq >> 1), 8);                                 // tap 9 has zero weights: any valid address
+        boff[j] = (uint32_t)(((tap / 3) * IW + fr * S + tap % 3) * PITCH + (fq & 1) * 16);
+    }
+    const char* const e_wr = Es + fr * PITCH + fq * 16;                            // S1 writes / S3-style fragment reads: + 16 m * PITCH
+    const char* const d_rd = Ds + fr * PITCH + fq * 16;
+    char* const d_wr = Ds + fr * PITCH + 8 * fq;                                   // + (16 u) * PITCH + 32 g
+    const char* const we_rd = Wes + fr * PITCH + fq * 16;
+    const char* const wp_rd = Wps + fr * PITCH + fq * 16;
+
+    const int nWavesAll = gridDim.x * nWaves;
+    int tile = blockIdx.x * nWaves + wave;
+
+    // ---- x fragments of tile t: global -> registers ---------------------------------------------------------------------------------
+    auto load_x = [&](int t, u32x4 (&xr)[NPT], uint32_t& vmask) __attribute__((always_inline)) {
+        const int tw = t % p.tilesW;
+        const int t2 = t / p.tilesW;
+        const int th = t2 % p.tilesH;
+        const int n = t2 / p.tilesH;
+        const int hi0 = th * R * S - 1, wi0 = tw * 16 * S - 1;
+        const bool live = t < p.nTiles;
+        vmask = 0;
+#pragma unroll
+        for (int m = 0; m < NPT; ++m) {
+            const int hi = hi0 + (int)(prc[m] >> 8), wi = wi0 + (int)(prc[m] & 255u);
+            const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            vmask |= ok ? (1u << m) : 0u;
+            const uint32_t off = (ok && 8 * fq < p.Cin) ? (uint32_t)(((((long)n * p.H + hi) * p.W + wi) * p.Cin + 8 * fq) * 2) : 0x80000000u;
+            xr[m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+        }
+    };
+
+    u32x4 xa[NPT];
+    uint32_t vm;
+    load_x(tile, xa, vm);
+
+    while (tile < p.nTiles) {
+        const int ntile = tile + nWavesAll;
+        u32x4 xb[NPT];
+        uint32_t vmn;
+        load_x(ntile, xb, vmn);                                                    // in flight during the whole tile
+
+        const int tw = tile % p.tilesW;
+        const int t2 = tile / p.tilesW;
+        const int th = t2 % p.tilesH;
+        const int n = t2 / p.tilesH;
+        const int ho0 = th * R, wo0 = tw * 16;
+        const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
+        const bool interior = hi0 >= 0 && hi0 + IH <= p.H && wi0 >= 0 && wi0 + IW <= p.W;     // wave-uniform
+
+        f32x4 acc[NRT][R];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+            for (int u = 0; u < R; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int c = 0; c < p.nChunks; ++c) {
+            // ---- S1: E chunk over the whole window ---------------------------------------------------------------------------------
+            {
+                const frag we0 = *reinterpret_cast<const frag*>(we_rd + (32 * c) * PITCH);
+                const frag we1 = *reinterpret_cast<const frag*>(we_rd + (32 * c + 16) * PITCH);
+                const f32x4 se0 = *reinterpret_cast<const f32x4*>(BNs + 32 * c + 8 * fq);
+                const f32x4 se1 = *reinterpret_cast<const f32x4*>(BNs + 32 * c + 8 * fq + 4);
+                const f32x4 he0 = *reinterpret_cast<const f32x4*>(BNs + CmidP + 32 * c + 8 * fq);
+                const f32x4 he1 = *reinterpret_cast<const f32x4*>(BNs + CmidP + 32 * c + 8 * fq + 4);
+#pragma unroll
+                for (int m = 0; m < NPT; ++m) {
+                    const frag b = __builtin_bit_cast(frag, xa[m]);
+                    const f32x4 e0 = Mma<DT>::run(we0, b, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    const f32x4 e1 = Mma<DT>::run(we1, b, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = e0[e] * se0[e] + he0[e];
+                        v[4 + e] = e1[e] * se1[e] + he1[e];
+                    }
+                    apply_act8(v, act_e);
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                    if (!interior) {
+                        const bool ok = (vm >> m) & 1u;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = ok ? o[e] : 0u;
+                    }
+                    *reinterpret_cast<u32x4*>(const_cast<char*>(e_wr) + 16 * m * PITCH) = o;
+                }
+            }
+            // ---- S2: depthwise 3x3 of the E chunk -> D chunk -------------------------------------------------------------------------
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                frag af[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const uint32_t w16 = *reinterpret_cast<const uint16_t*>(a_w + (2 * j * CmidP + 32 * c + 16 * g) * 2);
+                    const uint32_t val = w16 << a_sh;
+                    u32x4 a4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a4[i] = val & am[i];
+                    af[j] = __builtin_bit_cast(frag, a4);
+                }
+                const f32x4 sd = *reinterpret_cast<const f32x4*>(BNs + 2 * CmidP + 32 * c + 16 * g + 4 * fq);
+                const f32x4 hd = *reinterpret_cast<const f32x4*>(BNs + 3 * CmidP + 32 * c + 16 * g + 4 * fq);
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    f32x4 da = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const frag b = *reinterpret_cast<const frag*>(Es + boff[j] + (u * S * IW) * PITCH + 32 * g);
+                        da = Mma<DT>::run(af[j], b, da);
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
+                    apply_actn<4>(v, act_d);
+                    u32x2 o;
+                    o[0] = pack2<DT>(v[0], v[1]);
+                    o[1] = pack2<DT>(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(d_wr + (16 * u) * PITCH + 32 * g) = o;
+                }
+            }
+            // ---- S3: project GEMM, K step = this chunk ---------------------------------------------------------------------------------
+            {
+                frag wp[NRT];
+#pragma unroll
+                for (int i = 0; i < NRT; ++i) wp[i] = *reinterpret_cast<const frag*>(wp_rd + ((c * NRT + i) * 16) * PITCH);
+#pragma unroll
+                for (int u = 0; u < R; ++u) {
+                    const frag b = *reinterpret_cast<const frag*>(d_rd + (16 * u) * PITCH);
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i) acc[i][u] = Mma<DT>::run(wp[i], b, acc[i][u]);
+                }
+            }
+        }
+
+        // ---- epilogue: BN (+ residual), 16-byte NHWC stores ---------------------------------------------------------------------------
+#pragma unroll
+        for (int ipp = 0; ipp < NRT / 2; ++ipp) {
+            const int ch = 32 * ipp + 8 * fq;
+            f32x4 sp[2], hp[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sp[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sprsrc, (uint32_t)((ch + 4 * h) * 4), 0, 0));
+                hp[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hprsrc, (uint32_t)((ch + 4 * h) * 4), 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int ho = ho0 + u, wo = wo0 + fr;
+                const bool ok = ch < p.Cout && ho < p.Ho && wo < p.Wo;
+                const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wo) * p.Cout + ch) * 2) : 0x80000000u;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * ipp][u][e] * sp[0][e] + hp[0][e];
+                    v[4 + e] = acc[2 * ipp + 1][u][e] * sp[1][e] + hp[1][e];
+                }
+                apply_act8(v, act_p);
+                if (p.res != nullptr) {
+                    const u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float r0, r1;
+                        unpack2<DT>(rv[e], r0, r1);
+                        v[2 * e] += r0;
+                        v[2 * e + 1] += r1;
+                    }
+                    apply_act8(v, post);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off, 0, 0);
+            }
+        }
+
+        tile = ntile;
+#pragma unroll
+        for (int m = 0; m < NPT; ++m) xa[m] = xb[m];
+        vm = vmn;
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}

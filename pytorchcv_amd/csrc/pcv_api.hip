@@ -15,6 +15,7 @@
 #include "wpair1x1.hpp"
 #include "gconv3x3.hpp"
 #include "mbconv.hpp"
+#include "mbw.hpp"
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 #include "head_gemm.hpp"
@@ -33,6 +34,7 @@ struct pcv_ctx {
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp); 0: mbconv.hpp
     int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
@@ -489,6 +491,22 @@ static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
     if (dt == PCV_BF16) return nrowt <= 2 ? mbconv_for<PCV_BF16, 2>(stride, expand) : mbconv_for<PCV_BF16, 6>(stride, expand);
     return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
 }
+// wave-private variant (mbw.hpp): Cin <= 32, Cout <= 64
+static mbconv_fn pick_mbw(int dt, int stride, int nrt) {
+    if (dt == PCV_BF16) {
+        if (stride == 1) return nrt <= 2 ? mbw_kernel<PCV_BF16, 1, 2> : mbw_kernel<PCV_BF16, 1, 4>;
+        return nrt <= 2 ? mbw_kernel<PCV_BF16, 2, 2> : mbw_kernel<PCV_BF16, 2, 4>;
+    }
+    if (stride == 1) return nrt <= 2 ? mbw_kernel<PCV_F16, 1, 2> : mbw_kernel<PCV_F16, 1, 4>;
+    return nrt <= 2 ? mbw_kernel<PCV_F16, 2, 2> : mbw_kernel<PCV_F16, 2, 4>;
+}
+static const int kMbwMaxLds = 160 * 1024;
+// waves per block (one block per CU): as many of 8 / 6 / 4 as the LDS holds beside the unit's weights; 0 = does not fit
+static int mbw_waves(int stride, int nrt, int nChunks) {
+    for (int nw = 8; nw >= 4; nw -= 2)
+        if (mbw_lds_layout(stride, nrt, nChunks, nw).total <= kMbwMaxLds) return nw;
+    return 0;
+}
 static const int kMbMaxLds = 150 * 1024;
 // LDS plan of one unit: prefetch the next tile's x (two buffers) when that still leaves room for two blocks per CU
 static MbLds mbconv_plan(int stride, bool expand, int ka, int nChunks, int nRowT, int* nbufX) {
@@ -506,6 +524,11 @@ static int enable_mbconv(pcv_ctx* ctx) {
                 for (int rt = 2; rt <= 6; rt += 4)
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbconv(dt, s, e != 0, rt)),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMbMaxLds));
+    for (int dt = PCV_BF16; dt <= PCV_F16; ++dt)
+        for (int s = 1; s <= 2; ++s)
+            for (int rt = 2; rt <= 4; rt += 2)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbw(dt, s, rt)),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
     return PCV_OK;
 }
 // de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
@@ -635,6 +658,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "head") ctx->use_head = value;
+    else if (k == "mbw") ctx->use_mbw = value;
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
     else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;
@@ -1566,6 +1590,24 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     p.act_e = d_exp ? d_exp->act : 0; p.act_d = d_dw->act; p.act_p = d_proj->act; p.post = d_proj->post_act;
     if (p.nRowT > 6 || (d_exp && p.Kpad1 < 32 * p.ka) || p.Kpad2 < 32 * p.nChunks)
         return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
+    // wave-private tiles (mbw.hpp) where the unit qualifies: one K step of expand input, at most 64 projected channels
+    if (ctx->use_mbw && d_exp && p.Cin <= 32 && p.nRowT <= 4 && p.H <= 250 && p.W <= 250) {
+        const int nrt = p.nRowT <= 2 ? 2 : 4;
+        const int nw = mbw_waves(S, nrt, p.nChunks);
+        if (nw > 0) {
+            const int R = S == 1 ? 4 : 2;
+            p.tilesH = (p.Ho + R - 1) / R; p.tilesW = (p.Wo + 15) / 16;
+            const long nT = (long)p.N * p.tilesH * p.tilesW;
+            if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
+            p.nTiles = (int)nT;
+            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw);
+            const long want = (nT + nw - 1) / nw;
+            const unsigned gridw = (unsigned)std::min<long>(want, (long)block_slots(ctx, 1));
+            hipLaunchKernelGGL(pick_mbw(d_dw->dtype, S, nrt), dim3(gridw), dim3(64 * nw), wl.total, (hipStream_t)stream, p);
+            HIP_TRY(ctx, hipGetLastError());
+            return PCV_OK;
+        }
+    }
     const MbLds lds = mbconv_plan(S, d_exp != nullptr, p.ka, p.nChunks, p.nRowT, &p.nbufX);
     mbconv_fn fn = pick_mbconv(d_dw->dtype, S, d_exp != nullptr, p.nRowT);
     int nb = 0;

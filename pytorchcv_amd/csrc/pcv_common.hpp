@@ -67,8 +67,8 @@ template <int DT> __device__ __forceinline__ void store_elem(void* base, size_t 
 // ---- activations (reference: pytorchcv/models/common/activ.py) ------------------------------------------
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case PCV_ACT_RELU: return v < 0.f ? 0.f : v;                               // activ.py:64 (NaN stays NaN, as in torch)
-        case PCV_ACT_RELU6: return v != v ? v : fminf(fmaxf(v, 0.f), 6.f);         // activ.py:81
+        case PCV_ACT_RELU: return __builtin_elementwise_maximum(v, 0.f);           // activ.py:64 (NaN stays NaN, as in torch)
+        case PCV_ACT_RELU6: return __builtin_elementwise_minimum(__builtin_elementwise_maximum(v, 0.f), 6.f);   // activ.py:81
         case PCV_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __expf(-v));        // activ.py:132 (v_rcp_f32: 1 ulp)
         case PCV_ACT_SWISH: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));      // activ.py:20-21
         case PCV_ACT_HSIGMOID: return v != v ? v : fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);      // activ.py:29-30
@@ -76,10 +76,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         default: return v;
     }
 }
-// The common activations (none / relu / relu6) with launch-uniform codes: no activation is no instruction, ReLU is a compare +
-// select, ReLU6 a v_med3_f32 + a NaN patch - all NaN-PROPAGATING like torch's relu / hardtanh (v_max_f32 / v_med3_f32 alone
-// return the non-NaN operand, which would turn a NaN accumulator - corrupt weights, overflowed activations - into 0 / -inf
-// and hide it from every isfinite check downstream). One uniform branch per group, none per element.
+// The common activations (none / relu / relu6) with launch-uniform codes: no activation is no instruction, ReLU is one
+// v_maximum3_f32, ReLU6 adds one v_minimum3_f32 - gfx950's IEEE-754-2019 maximum / minimum, which PROPAGATE NaN like torch's
+// relu / hardtanh (v_max_f32 / v_med3_f32 return the non-NaN operand, which would turn a NaN accumulator - corrupt weights,
+// overflowed activations - into 0 and hide it from every isfinite check downstream). One uniform branch per group, none per element.
 struct ActClamp {
     float lo, hi;
     bool slow;
@@ -97,13 +97,10 @@ template <int N> __device__ __forceinline__ void clampn(float (&v)[N], const Act
     if (a.code == PCV_ACT_NONE) return;
     if (a.code == PCV_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < N; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];                 // NaN compares false: stays NaN
+        for (int e = 0; e < N; ++e) v[e] = __builtin_elementwise_maximum(v[e], 0.f);
     } else {
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const float r = __builtin_amdgcn_fmed3f(v[e], 0.f, 6.f);
-            v[e] = v[e] != v[e] ? v[e] : r;
-        }
+        for (int e = 0; e < N; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), 6.f);
     }
 }
 // the non-clamp activations: ONE uniform switch around a straight unrolled run per case (a switch per element costs eight

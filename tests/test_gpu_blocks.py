@@ -310,15 +310,18 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
     (2, 28, 28, 24, True, 24, 1, "relu6"), (2, 56, 56, 16, True, 24, 2, "relu6"), (2, 30, 27, 32, False, 16, 1, "relu6"),
     (1, 28, 28, 48, True, 32, 1, "relu6"), (3, 59, 53, 24, True, 32, 2, "hswish"), (1, 112, 112, 32, False, 16, 1, "relu"),
     (2, 33, 47, 40, True, 24, 1, "relu"), (2, 56, 56, 40, True, 32, 2, "relu6"), (1, 28, 28, 96, True, 32, 1, None),
+    (2, 61, 45, 32, True, 32, 1, "relu6"), (1, 112, 112, 16, True, 24, 2, "relu6"), (5, 56, 56, 24, True, 24, 1, "relu6"),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("kernel", ["wave", "block"])
 @pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
-def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, grid, cuda_device):
+def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype, grid, cuda_device):
     """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
-    launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle."""
+    launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle.
+    `kernel`: wave-private tiles (csrc/mbw.hpp, units with at most 32 input channels) or block tiles (csrc/mbconv.hpp)."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
@@ -337,7 +340,7 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, dtype, grid, c
     a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
     residual = a if unit.residual else None
     with torch.no_grad():
-        with util.tuning(max_blocks=grid):
+        with util.tuning(max_blocks=grid, mbw=1 if kernel == "wave" else 0):
             fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
         if act is None:
             assert fused is None, "576 expanded channels x 96 inputs do not fit the LDS budget: must fall back"
