@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
     while (true) {
         // ---- K-steps 0 .. nk-2: tight loop, one barrier each --------------------------------------------------
         for (int k = 0; k + 1 < nk; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // LDS-DMA completion is a vmcnt event: say so, do not leave it to the compiler
             __syncthreads();                   // DMA(k) landed for every wave; the other stage is free again
             stage(cur, k + 1, buf ^ 1);
             if constexpr (KHW == 0) kd_next = load_kdesc(k + 2 < nk ? k + 2 : 0);    // (k+2 == nk: next tile's step 0)
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
         const int ntile = tile + tstride;
         const bool has_next = ntile < tend;
         if (has_next) setup(ntile, nxt);       // address math overlaps the DMA wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         // Packed weight row (16*i + rho) of a 64-row group holds channel 32*(i>>1) + 8*(rho>>2) + 4*(i&1) + (rho&3), so

@@ -4,11 +4,12 @@
 //
 // mbconv.hpp's block owns a TH x 16 output tile and its four waves meet at two barriers per 32-channel chunk; with 5 pixel blocks
 // of expand work per wave between barriers the unit ran at 7-8 K cycles per chunk for ~1.5 K cycles of instructions (16 -> 96 ->
-// 24 at 112x112: 559 us against a 70 us HBM floor). Here every wave owns an R x 16 output tile (R = 4 rows at stride 1, 2 at
-// stride 2) and keeps its own E / D chunk tiles in LDS, so its three stages are one straight instruction stream (LDS operations
-// of a wave execute in order: no barrier, no explicit wait), and eight such waves per CU hide each other's latencies. The price
-// is the expand work of the halo rows that neighbouring waves no longer share (1.75 / 5.2 expanded pixels per output at stride
-// 1 / 2 instead of 1.4 / 4.6).
+// 24 at 112x112: 559 us against a 70 us HBM floor). Here every wave owns a tile of 4 (stride 1) or 2 (stride 2) MFMA pixel blocks
+// - a pixel block is 1 row x 16 columns (TW = 16) or 2 rows x 8 columns (TW = 8: a 56-wide map is 7 x 8 with no ragged column
+// tile, and the stride-2 window shrinks from 5 x 33 to 9 x 17 pixels) - and keeps its own E / D chunk tiles in LDS, so its
+// three stages are one straight instruction stream (LDS operations of a wave execute in order: no barrier, no explicit wait),
+// and eight such waves per CU hide each other's latencies. The price is the expand work of the halo rows that neighbouring waves
+// no longer share (1.6-1.7 / 4.8-5.2 expanded pixels per output at stride 1 / 2 instead of 1.4 / 4.6).
 //
 //   x   the window's pixels go global -> registers as MFMA B fragments (lane = pixel l % 16, channels 8 (l / 16) .. + 7; padding and
 //       channel tails = out-of-range buffer offsets = zeros), prefetched one tile ahead. No LDS staging: Cin <= 32 is one K step.
@@ -27,8 +28,13 @@
 struct MbwLds {
     int wexp, wproj, wdw, bn, wave0, per_wave, total;
 };
-static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves) {
-    const int npt = stride == 1 ? 7 : 11, rows = stride == 1 ? 4 : 2;
+// 16-pixel blocks over the input window of a wave tile
+static inline __host__ __device__ int mbw_npt(int stride, int tw) {
+    const int nblk = stride == 1 ? 4 : 2, ro = nblk * (16 / tw);
+    return (((ro - 1) * stride + 3) * ((tw - 1) * stride + 3) + 15) / 16;          // 7 / 7 (stride 1), 11 / 10 (stride 2)
+}
+static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves, int tw) {
+    const int npt = mbw_npt(stride, tw), rows = stride == 1 ? 4 : 2;
     MbwLds L;
     int o = 0;
     L.wexp = o; o += nChunks * 32 * 80;                           // [chunk][32 rows]
@@ -42,19 +48,37 @@ static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int
     return L;
 }
 
-// S: stride; NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64). Cin <= 32. blockDim.x = 64 * waves.
-template <int DT, int S, int NRT>
+// The activation behind the expand and the depthwise stage as a compile-time constant: with the launch-time code every one of the
+// 11 + 4 unrolled applications per chunk was a nest of scalar branches (580 basic blocks), and nothing could be scheduled across them.
+template <int ACT, int N> __device__ __forceinline__ void mbw_act(float (&v)[N], const ActClamp& dyn) {
+    if constexpr (ACT == PCV_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = __builtin_elementwise_maximum(v[e], 0.f);
+    } else if constexpr (ACT == PCV_ACT_RELU6) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), 6.f);
+    } else {
+        apply_actn<N>(v, dyn);
+    }
+}
+
+// S: stride; NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise
+// stages when both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; TW: columns of a pixel block (16 or 8). Cin <= 32.
+// blockDim.x = 64 * waves.
+template <int DT, int S, int NRT, int ACT, int TW>
 __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int R = S == 1 ? 4 : 2;                   // output rows per wave tile (x 16 columns)
-    constexpr int IH = (R - 1) * S + 3, IW = 15 * S + 3;
-    constexpr int NIP = IH * IW;                        // window pixels: 108 / 165
-    constexpr int NPT = (NIP + 15) / 16;                // 7 / 11
+    constexpr int R = S == 1 ? 4 : 2;                   // pixel blocks per wave tile
+    constexpr int PR = 16 / TW;                         // output rows of a pixel block
+    constexpr int RO = R * PR;                          // output rows of the tile
+    constexpr int IH = (RO - 1) * S + 3, IW = (TW - 1) * S + 3;
+    constexpr int NIP = IH * IW;                        // window pixels: 108 / 100 (stride 1), 165 / 153 (stride 2)
+    constexpr int NPT = (NIP + 15) / 16;
     constexpr int PITCH = 80;
     typedef typename Mma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nWaves = blockDim.x >> 6;
-    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves);
+    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves, TW);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,7 +135,8 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     }
     // S2: A (weights, rows = channels) lane (row fr, k quarter fq) holds tap (fq >> 1) of the pair, channels 8 (fq & 1) .. + 7 of the
     // 16-channel half: non-zero only on the diagonal, element fr & 7 when (fr >> 3) == (fq & 1). B (E tile, columns = the 16 pixels
-    // of one output row): lane (column fr, fq) reads the same 8 channels of the pixel under its tap.
+    // of one pixel block): lane (pixel fr, fq) reads the same 8 channels of the input pixel under its tap.
+    const int pr = fr / TW, pc = fr % TW;                                          // this lane's pixel inside a pixel block
     uint32_t am[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) am[i] = ((fr >> 3) == (fq & 1) && i == ((fr & 7) >> 1)) ? 0xFFFFFFFFu : 0u;
@@ -121,7 +146,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int tap = min(2 * j + (fq >> 1), 8);                                 // tap 9 has zero weights: any valid address
-        boff[j] = (uint32_t)(((tap / 3) * IW + fr * S + tap % 3) * PITCH + (fq & 1) * 16);
+        boff[j] = (uint32_t)(((pr * S + tap / 3) * IW + pc * S + tap % 3) * PITCH + (fq & 1) * 16);
     }
     const char* const e_wr = Es + fr * PITCH + fq * 16;                            // S1 writes / S3-style fragment reads: + 16 m * PITCH
     const char* const d_rd = Ds + fr * PITCH + fq * 16;
@@ -138,16 +163,17 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
         const int t2 = t / p.tilesW;
         const int th = t2 % p.tilesH;
         const int n = t2 / p.tilesH;
-        const int hi0 = th * R * S - 1, wi0 = tw * 16 * S - 1;
+        const int hi0 = th * RO * S - 1, wi0 = tw * TW * S - 1;
         const bool live = t < p.nTiles;
+        const bool chans = 8 * fq < p.Cin;
         vmask = 0;
 #pragma unroll
         for (int m = 0; m < NPT; ++m) {
             const int hi = hi0 + (int)(prc[m] >> 8), wi = wi0 + (int)(prc[m] & 255u);
-            const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const bool ok = live & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);      // (no short circuit: no branches)
             vmask |= ok ? (1u << m) : 0u;
-            const uint32_t off = (ok && 8 * fq < p.Cin) ? (uint32_t)(((((long)n * p.H + hi) * p.W + wi) * p.Cin + 8 * fq) * 2) : 0x80000000u;
-            xr[m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+            const uint32_t off = (uint32_t)((((n * p.H + hi) * p.W + wi) * p.Cin + 8 * fq) * 2);        // < 2 GiB: checked by the host
+            xr[m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (ok & chans) ? off : 0x80000000u, 0, 0);
         }
     };
 
@@ -165,9 +191,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
         const int t2 = tile / p.tilesW;
         const int th = t2 % p.tilesH;
         const int n = t2 / p.tilesH;
-        const int ho0 = th * R, wo0 = tw * 16;
-        const int hi0 = ho0 * S - 1, wi0 = wo0 * S - 1;
-        const bool interior = hi0 >= 0 && hi0 + IH <= p.H && wi0 >= 0 && wi0 + IW <= p.W;     // wave-uniform
+        const int ho0 = th * RO, wo0 = tw * TW;
 
         f32x4 acc[NRT][R];
 #pragma unroll
@@ -190,20 +214,31 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                     const frag b = __builtin_bit_cast(frag, xa[m]);
                     const f32x4 e0 = Mma<DT>::run(we0, b, (f32x4){0.f, 0.f, 0.f, 0.f});
                     const f32x4 e1 = Mma<DT>::run(we1, b, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    // BN as packed fma (v_pk_fma_f32); pixels outside the image must come out 0 (the depthwise pads the EXPANDED map)
+                    f32x2 t[4];
+                    t[0] = (f32x2){e0[0], e0[1]} * (f32x2){se0[0], se0[1]} + (f32x2){he0[0], he0[1]};
+                    t[1] = (f32x2){e0[2], e0[3]} * (f32x2){se0[2], se0[3]} + (f32x2){he0[2], he0[3]};
+                    t[2] = (f32x2){e1[0], e1[1]} * (f32x2){se1[0], se1[1]} + (f32x2){he1[0], he1[1]};
+                    t[3] = (f32x2){e1[2], e1[3]} * (f32x2){se1[2], se1[3]} + (f32x2){he1[2], he1[3]};
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = e0[e] * se0[e] + he0[e];
-                        v[4 + e] = e1[e] * se1[e] + he1[e];
+                        v[2 * e] = t[e][0];
+                        v[2 * e + 1] = t[e][1];
                     }
-                    apply_act8(v, act_e);
+                    const bool ok = (vm >> m) & 1u;
                     u32x4 o;
+                    if constexpr (ACT == PCV_ACT_RELU || ACT == PCV_ACT_RELU6) {
+                        // the clamp's upper bound doubles as the mask: min(max(v, 0), ok ? 6 : 0) - one select per pixel block
+                        const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-                    if (!interior) {
-                        const bool ok = (vm >> m) & 1u;
+                        for (int e = 0; e < 8; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), hi);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = ok ? o[e] : 0u;
+                        for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                    } else {
+                        apply_act8(v, act_e);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = ok ? pack2<DT>(v[2 * e], v[2 * e + 1]) : 0u;
                     }
                     *reinterpret_cast<u32x4*>(const_cast<char*>(e_wr) + 16 * m * PITCH) = o;
                 }
@@ -228,13 +263,13 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                     f32x4 da = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
-                        const frag b = *reinterpret_cast<const frag*>(Es + boff[j] + (u * S * IW) * PITCH + 32 * g);
+                        const frag b = *reinterpret_cast<const frag*>(Es + boff[j] + (u * PR * S * IW) * PITCH + 32 * g);
                         da = Mma<DT>::run(af[j], b, da);
                     }
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
-                    apply_actn<4>(v, act_d);
+                    mbw_act<ACT, 4>(v, act_d);
                     u32x2 o;
                     o[0] = pack2<DT>(v[0], v[1]);
                     o[1] = pack2<DT>(v[2], v[3]);
@@ -267,7 +302,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int ho = ho0 + u, wo = wo0 + fr;
+                const int ho = ho0 + u * PR + pr, wo = wo0 + pc;
                 const bool ok = ch < p.Cout && ho < p.Ho && wo < p.Wo;
                 const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wo) * p.Cout + ch) * 2) : 0x80000000u;
                 float v[8];

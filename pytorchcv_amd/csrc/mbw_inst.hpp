@@ -1,0 +1,12 @@
+// mbw_inst.hpp - the instantiations of mbw_kernel (mbw_bf16.hip / mbw_f16.hip define them, pcv_api.hip sees `extern template`).
+//   X(DT, S, NRT, ACT, TW): stride, 16-row tiles of the projection, compile-time inner activation (-1: launch-time), pixel-block width
+#pragma once
+#include "mbw.hpp"
+
+#define MBW_SHAPES3(X, DT, S, NRT) \
+    X(DT, S, NRT, -1, 16) X(DT, S, NRT, -1, 8) X(DT, S, NRT, PCV_ACT_RELU, 16) X(DT, S, NRT, PCV_ACT_RELU, 8) \
+    X(DT, S, NRT, PCV_ACT_RELU6, 16) X(DT, S, NRT, PCV_ACT_RELU6, 8)
+#define MBW_SHAPES(X, DT) MBW_SHAPES3(X, DT, 1, 2) MBW_SHAPES3(X, DT, 1, 4) MBW_SHAPES3(X, DT, 2, 2) MBW_SHAPES3(X, DT, 2, 4)
+
+#define MBW_DEFINE(DT, S, NRT, ACT, TW) template __global__ void mbw_kernel<DT, S, NRT, ACT, TW>(const MbParams);
+#define MBW_DECLARE(DT, S, NRT, ACT, TW) extern template __global__ void mbw_kernel<DT, S, NRT, ACT, TW>(const MbParams);

@@ -15,7 +15,9 @@
 #include "wpair1x1.hpp"
 #include "gconv3x3.hpp"
 #include "mbconv.hpp"
-#include "mbw.hpp"
+#include "mbw_inst.hpp"
+MBW_SHAPES(MBW_DECLARE, PCV_BF16)
+MBW_SHAPES(MBW_DECLARE, PCV_F16)
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 #include "head_gemm.hpp"
@@ -34,7 +36,7 @@ struct pcv_ctx {
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
-    int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp); 0: mbconv.hpp
+    int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp; 8 / 16: force that pixel-block width); 0: mbconv.hpp
     int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
@@ -492,19 +494,21 @@ static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
     return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
 }
 // wave-private variant (mbw.hpp): Cin <= 32, Cout <= 64
-static mbconv_fn pick_mbw(int dt, int stride, int nrt) {
-    if (dt == PCV_BF16) {
-        if (stride == 1) return nrt <= 2 ? mbw_kernel<PCV_BF16, 1, 2> : mbw_kernel<PCV_BF16, 1, 4>;
-        return nrt <= 2 ? mbw_kernel<PCV_BF16, 2, 2> : mbw_kernel<PCV_BF16, 2, 4>;
-    }
-    if (stride == 1) return nrt <= 2 ? mbw_kernel<PCV_F16, 1, 2> : mbw_kernel<PCV_F16, 1, 4>;
-    return nrt <= 2 ? mbw_kernel<PCV_F16, 2, 2> : mbw_kernel<PCV_F16, 2, 4>;
+struct MbwEntry { int dt, s, nrt, act, tw; mbconv_fn fn; };
+#define MBW_ROW(DT, S, NRT, ACT, TW) {DT, S, NRT, ACT, TW, mbw_kernel<DT, S, NRT, ACT, TW>},
+static const MbwEntry kMbw[] = {MBW_SHAPES(MBW_ROW, PCV_BF16) MBW_SHAPES(MBW_ROW, PCV_F16)};
+// act: PCV_ACT_RELU / PCV_ACT_RELU6 when both inner activations are that one, anything else = the launch-time codes
+static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw) {
+    if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
+    for (const MbwEntry& e : kMbw)
+        if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw) return e.fn;
+    return nullptr;
 }
 static const int kMbwMaxLds = 160 * 1024;
 // waves per block (one block per CU): as many of 8 / 6 / 4 as the LDS holds beside the unit's weights; 0 = does not fit
-static int mbw_waves(int stride, int nrt, int nChunks) {
+static int mbw_waves(int stride, int nrt, int nChunks, int tw) {
     for (int nw = 8; nw >= 4; nw -= 2)
-        if (mbw_lds_layout(stride, nrt, nChunks, nw).total <= kMbwMaxLds) return nw;
+        if (mbw_lds_layout(stride, nrt, nChunks, nw, tw).total <= kMbwMaxLds) return nw;
     return 0;
 }
 static const int kMbMaxLds = 150 * 1024;
@@ -524,11 +528,8 @@ static int enable_mbconv(pcv_ctx* ctx) {
                 for (int rt = 2; rt <= 6; rt += 4)
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbconv(dt, s, e != 0, rt)),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMbMaxLds));
-    for (int dt = PCV_BF16; dt <= PCV_F16; ++dt)
-        for (int s = 1; s <= 2; ++s)
-            for (int rt = 2; rt <= 4; rt += 2)
-                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbw(dt, s, rt)),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
+    for (const MbwEntry& e : kMbw)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
     return PCV_OK;
 }
 // de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
@@ -1593,17 +1594,24 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     // wave-private tiles (mbw.hpp) where the unit qualifies: one K step of expand input, at most 64 projected channels
     if (ctx->use_mbw && d_exp && p.Cin <= 32 && p.nRowT <= 4 && p.H <= 250 && p.W <= 250) {
         const int nrt = p.nRowT <= 2 ? 2 : 4;
-        const int nw = mbw_waves(S, nrt, p.nChunks);
+        // pixel-block shape: 1 x 16 or 2 x 8 outputs, whichever covers the map with less expand work (window blocks x tiles)
+        const int nblk = S == 1 ? 4 : 2;
+        auto tiles_of = [&](int tw) { return (long)((p.Ho + nblk * (16 / tw) - 1) / (nblk * (16 / tw))) * ((p.Wo + tw - 1) / tw); };
+        int tw = mbw_npt(S, 8) * tiles_of(8) < mbw_npt(S, 16) * tiles_of(16) ? 8 : 16;
+        if (ctx->use_mbw == 8 || ctx->use_mbw == 16) tw = ctx->use_mbw;
+        const int nw = mbw_waves(S, nrt, p.nChunks, tw);
         if (nw > 0) {
-            const int R = S == 1 ? 4 : 2;
-            p.tilesH = (p.Ho + R - 1) / R; p.tilesW = (p.Wo + 15) / 16;
+            const int RO = nblk * (16 / tw);
+            p.tilesH = (p.Ho + RO - 1) / RO; p.tilesW = (p.Wo + tw - 1) / tw;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
-            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw);
+            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw, tw);
             const long want = (nT + nw - 1) / nw;
             const unsigned gridw = (unsigned)std::min<long>(want, (long)block_slots(ctx, 1));
-            hipLaunchKernelGGL(pick_mbw(d_dw->dtype, S, nrt), dim3(gridw), dim3(64 * nw), wl.total, (hipStream_t)stream, p);
+            mbconv_fn fnw = pick_mbw(d_dw->dtype, S, nrt, p.act_e == p.act_d ? p.act_e : -1, tw);
+            if (!fnw) return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: no kernel instantiation");
+            hipLaunchKernelGGL(fnw, dim3(gridw), dim3(64 * nw), wl.total, (hipStream_t)stream, p);
             HIP_TRY(ctx, hipGetLastError());
             return PCV_OK;
         }

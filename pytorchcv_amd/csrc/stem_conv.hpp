@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
     while (true) {
         const int ntile = tile + tstride;
         const bool has_next = ntile < tend;
+        // The LDS-DMA of this tile's patch (issued one tile ago) is tracked by vmcnt only: __syncthreads() alone is a workgroup
+        // fence (lgkmcnt) + barrier, and without this wait the loop had NO vmcnt wait at all - a block's later tiles could read a
+        // patch whose last pieces were still in flight (seen once in ~6 full-batch forwards as a few wrong output rows).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // weights + this tile's patch landed; other buffer free
         if (has_next) issue_patch(ntile, buf ^ 1);
 

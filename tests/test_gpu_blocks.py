@@ -316,12 +316,13 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["wave", "block"])
+@pytest.mark.parametrize("kernel", ["wave", "wave8", "wave16", "block"])
 @pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
 def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype, grid, cuda_device):
     """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
     launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle.
-    `kernel`: wave-private tiles (csrc/mbw.hpp, units with at most 32 input channels) or block tiles (csrc/mbconv.hpp)."""
+    `kernel`: wave-private tiles (csrc/mbw.hpp, units with at most 32 input channels; pixel blocks of 2 x 8 or 1 x 16 outputs,
+    chosen by the library or forced) or block tiles (csrc/mbconv.hpp)."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
@@ -340,7 +341,7 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype,
     a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
     residual = a if unit.residual else None
     with torch.no_grad():
-        with util.tuning(max_blocks=grid, mbw=1 if kernel == "wave" else 0):
+        with util.tuning(max_blocks=grid, mbw={"wave": 1, "wave8": 8, "wave16": 16, "block": 0}[kernel]):
             fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
         if act is None:
             assert fused is None, "576 expanded channels x 96 inputs do not fit the LDS budget: must fall back"
@@ -529,3 +530,25 @@ def test_fp32_head_gemm_vs_generic_and_fp64(shape, cuda_device):
     assert float((y_head - y_gen).abs().max()) <= 2e-5 * scale
     pieces = [run(xd[i:i + 5].contiguous(), head=1) for i in range(0, N, 5)]
     assert torch.equal(torch.cat(pieces), y_head)
+
+
+@pytest.mark.parametrize("kind", ["mobilenet3x3", "resnet7x7pool"])
+def test_stem_full_batch_is_repeatable(kind, cuda_device):
+    """The stem kernel at the benchmark batch, ten times: every image of every pass equals the 4-image forward bit for bit.
+    (A missing vmcnt wait before the tile barrier of csrc/stem_conv.hpp let a block's later tiles read a patch whose last LDS-DMA
+    pieces were still in flight: a few wrong rows in one of ~6 full-batch forwards.)"""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from pytorchcv_amd.models.resnet import ResInitBlock
+    blk = (conv3x3_block(in_channels=3, out_channels=32, stride=2) if kind == "mobilenet3x3" else ResInitBlock(3, 64)).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=3))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), "bf16")
+    batch = 256
+    x4 = util.synth_input(4, 3, 224, 224, seed=12).to(cuda_device)
+    x = x4.repeat(batch // 4, 1, 1, 1).contiguous()
+    with torch.no_grad():
+        want = blk(engine.from_nchw(x4, "bf16", stem=True)).t.repeat(batch // 4, 1, 1, 1)
+        for rep in range(10):
+            y = blk(engine.from_nchw(x, "bf16", stem=True)).t
+            assert torch.equal(y, want), "pass {}: {} images differ".format(rep, int((y != want).flatten(1).any(1).sum()))
