@@ -27,7 +27,7 @@ import torch.distributed as dist  # noqa: E402
 WORKLOADS = {
     # name: (model, per-GPU batch, kernel class for the roofline, bound)
     "resnet50_bs256": ("resnet50", 256, "dense3x3", "mfma"),
-    "mobilenetv2_w1_bs512": ("mobilenetv2_w1", 512, "depthwise", "hbm"),
+    "mobilenetv2_w1_bs512": ("mobilenetv2_w1", 512, "fused_unit", "hbm"),      # the fused inverted-residual units: 40 % of the step
     "resnext101_32x4d_bs256": ("resnext101_32x4d", 256, "grouped3x3", "hbm"),
     "resnet18_bs256": ("resnet18", 256, "dense3x3", "mfma"),
     "mobilenetv3_large_w1_bs512": ("mobilenetv3_large_w1", 512, "depthwise", "hbm"),
@@ -89,11 +89,34 @@ class LaunchTimer(object):
             return y
 
         engine.ConvRunner._launch = timed
+        # "fused_unit": the one-launch inverted-residual units (pcv_mbconv_fused). Algorithmic bytes = the unit's input and output
+        # once (the skip tensor IS the input) + the three weight sets; FLOPs = expand + depthwise + project.
+        self._orig_mb = engine.mbconv_fused
+
+        def timed_mb(exp, exp_act, dw, dw_act, proj, proj_act, x, residual, post_act):
+            if timer.klass != "fused_unit":
+                return timer._orig_mb(exp, exp_act, dw, dw_act, proj, proj_act, x, residual, post_act)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            y = timer._orig_mb(exp, exp_act, dw, dw_act, proj, proj_act, x, residual, post_act)
+            e.record()
+            if y is None:
+                return None
+            es = x.t.element_size()
+            cmid, cout = dw.conv.out_channels, proj.conv.out_channels
+            px_in, px_out = x.N * x.H * x.W, y.N * y.H * y.W
+            flops = 2.0 * ((px_in * x.C * cmid if exp is not None else 0) + px_out * cmid * 9 + px_out * cmid * cout)
+            nbytes = (px_in * x.C + px_out * cout + (x.C * cmid if exp is not None else 0) + 9 * cmid + cmid * cout) * es
+            timer.records.append((s, e, flops, nbytes, "{}x{}x{}->{}->{} s{}".format(x.H, x.W, x.C, cmid, cout, dw.conv.stride[0])))
+            return y
+
+        engine.mbconv_fused = timed_mb
         return self
 
     def __exit__(self, *a):
         from pytorchcv_amd import engine
         engine.ConvRunner._launch = self._orig
+        engine.mbconv_fused = self._orig_mb
 
     def summary(self):
         torch.cuda.synchronize()
@@ -184,7 +207,7 @@ def rocprof_class_us(workload, klass):
     import csv
     import glob
     names = {"dense3x3": ("d3q_kernel", "false, 9>"), "depthwise": ("dwconv_kernel", "dwconv5_kernel"),
-             "grouped3x3": ("gconv3x3_kernel",)}.get(klass)
+             "grouped3x3": ("gconv3x3_kernel",), "fused_unit": ("mbw_kernel", "mbconv_kernel")}.get(klass)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_{}_*kernel_stats*.csv".format(workload.replace("_bs", "_bs")))))
     if not names or not files:
         return None, None
@@ -314,7 +337,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f).get(args.workload)
-        if pmc is not None and (pmc.get("dtype") != args.dtype or args.batch > 0):
+        if pmc is not None and (pmc.get("dtype") != args.dtype or args.batch > 0 or pmc.get("kernel_class") != klass):
             pmc = None
     except (OSError, ValueError):
         pmc = None

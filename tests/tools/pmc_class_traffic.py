@@ -2,7 +2,7 @@
 
     python tests/tools/pmc_class_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <class> [skip]
 
-class: dense3x3 (igemm_conv_kernel<..., 9>), depthwise (dwconv_kernel), grouped3x3 (gconv3x3_kernel: the stride-1 grouped layers,
+class: dense3x3 (d3q_kernel + igemm_conv_kernel<..., 9>), fused_unit (mbw_kernel / mbconv_kernel), depthwise (dwconv_kernel), grouped3x3 (gconv3x3_kernel: the stride-1 grouped layers,
 29 of ResNeXt-101's 33 grouped launches; the stride-2 / 32-channels-per-group ones run on the generic kernel).
 Counters are reported in KB; FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes for 16 B/lane streaming
 reads - MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16 B/lane stores. The first `skip` matching launches
@@ -15,7 +15,9 @@ def pick(name, klass):
     if klass == "grouped3x3":
         return "gconv3x3_kernel" in name
     if klass == "dense3x3":
-        return "igemm_conv_kernel" in name and name.rstrip().rstrip(")").split("(")[0].rstrip().endswith(", 9>")
+        return "d3q_kernel" in name or ("igemm_conv_kernel" in name and name.rstrip().rstrip(")").split("(")[0].rstrip().endswith(", 9>"))
+    if klass == "fused_unit":
+        return "mbw_kernel" in name or "mbconv_kernel" in name
     if klass == "depthwise":
         return "dwconv_kernel" in name
     raise SystemExit("unknown class " + klass)
