@@ -552,10 +552,12 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
     if (!plain1x1(dp) || dp.dtype != dd.dtype || dp.Cin != Cmid || dp.Cout % 8 != 0 || dp.Cout > 96) return "project stage must be a plain 1x1 with at most 96 channels";
     // measured (MobileNetV2, batch 512): the fused unit wins on the large maps (the expanded tensor is what costs) and loses on
     // 14x14 and below / wide projections, where the three separate launches are cheap and this kernel is VALU-bound
-    if (dp.Cout > 32) return "fused unit only pays for narrow projections (<= 32 channels)";
+    // the wave-private kernel (mbw.hpp: at most 32 unit inputs, one expand K step) also takes 64 projected channels and 14x14 maps
+    const bool wave_tiles = de && de->Cin <= 32 && dd.H <= 250 && dd.W <= 250;
+    if (dp.Cout > (wave_tiles ? 64 : 32)) return "fused unit only pays for narrow projections";
     const int Ho = (dd.H - 1) / dd.stride_h + 1, Wo = (dd.W - 1) / dd.stride_w + 1;
     if (dp.N != dd.N || dp.H != Ho || dp.W != Wo) return "shapes do not chain";
-    if (Wo < 24 || Ho < 8) return "map too small for the fused unit to pay";
+    if (Wo < (wave_tiles ? 14 : 24) || Ho < 8) return "map too small for the fused unit to pay";
     int ka = 0;
     if (de) {
         if (!plain1x1(*de) || de->dtype != dd.dtype || de->Cout != Cmid || de->Cin % 8 != 0 || de->has_residual ||
