@@ -33,12 +33,14 @@ static inline __host__ __device__ int mbw_npt(int stride, int tw) {
     const int nblk = stride == 1 ? 4 : 2, ro = nblk * (16 / tw);
     return (((ro - 1) * stride + 3) * ((tw - 1) * stride + 3) + 15) / 16;          // 7 / 7 (stride 1), 11 / 10 (stride 2)
 }
-static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves, int tw) {
+// ka: K steps of the expand GEMM (Cin <= 32 ka). With ka == 1 the two 1x1 weight matrices live in LDS; wider units (64 -> 384 ->
+// 64 is 98 KB of weights) leave them in L2 and every wave fetches its fragments per chunk.
+static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves, int tw, int ka = 1) {
     const int npt = mbw_npt(stride, tw), rows = stride == 1 ? 4 : 2;
     MbwLds L;
     int o = 0;
-    L.wexp = o; o += nChunks * 32 * 80;                           // [chunk][32 rows]
-    L.wproj = o; o += nChunks * nrt * 16 * 80;                    // [chunk][nrt * 16 rows]
+    L.wexp = o; o += ka == 1 ? nChunks * 32 * 80 : 0;             // [chunk][32 rows]
+    L.wproj = o; o += ka == 1 ? nChunks * nrt * 16 * 80 : 0;      // [chunk][nrt * 16 rows]
     L.wdw = o; o += (10 * nChunks * 32 * 2 + 15) & ~15;           // [10][CmidP] 16-bit: tap 9 = zeros (second half of the last tap pair)
     L.bn = o; o += 4 * nChunks * 32 * 4;                          // scale_e, shift_e, scale_d, shift_d
     L.wave0 = o;
@@ -65,7 +67,7 @@ template <int ACT, int N> __device__ __forceinline__ void mbw_act(float (&v)[N],
 // S: stride; NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise
 // stages when both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; TW: columns of a pixel block (16 or 8). Cin <= 32.
 // blockDim.x = 64 * waves.
-template <int DT, int S, int NRT, int ACT, int TW>
+template <int DT, int S, int NRT, int ACT, int TW, int KA = 1>
 __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int R = S == 1 ? 4 : 2;                   // pixel blocks per wave tile
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     typedef typename Mma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nWaves = blockDim.x >> 6;
-    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves, TW);
+    constexpr bool WLDS = KA == 1;                      // 1x1 weights resident in LDS (else: fragments straight from L2)
+    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves, TW, KA);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,12 +104,12 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     const __amdgpu_buffer_rsrc_t hprsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift_p), 0, p.Cout * 4, 0x00020000);
 
     // ---- the unit's weights -> LDS, once per block (rows beyond the packed matrices / channels beyond Cmid read as zeros) --------
-    for (int i = tid; i < p.nChunks * 32 * 4; i += blockDim.x) {
+    for (int i = tid; WLDS && i < p.nChunks * 32 * 4; i += blockDim.x) {
         const int slot = i & 3, row = i >> 2;                                      // row = 32 c + r: packed row order = MFMA order
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wersrc, (uint32_t)((row * p.Kpad1 + 8 * slot) * 2), 0, 0);
         *reinterpret_cast<u32x4*>(Wes + row * PITCH + slot * 16) = v;
     }
-    for (int i = tid; i < p.nChunks * NRT * 16 * 4; i += blockDim.x) {
+    for (int i = tid; WLDS && i < p.nChunks * NRT * 16 * 4; i += blockDim.x) {
         const int slot = i & 3, row = (i >> 2) % (NRT * 16), c = (i >> 2) / (NRT * 16);
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wprsrc, (uint32_t)((row * p.Kpad2 + 32 * c + 8 * slot) * 2), 0, 0);
         *reinterpret_cast<u32x4*>(Wps + (c * NRT * 16 + row) * PITCH + slot * 16) = v;
@@ -158,14 +161,13 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     int tile = blockIdx.x * nWaves + wave;
 
     // ---- x fragments of tile t: global -> registers ---------------------------------------------------------------------------------
-    auto load_x = [&](int t, u32x4 (&xr)[NPT], uint32_t& vmask) __attribute__((always_inline)) {
+    auto load_x = [&](int t, u32x4 (&xr)[KA][NPT], uint32_t& vmask) __attribute__((always_inline)) {
         const int tw = t % p.tilesW;
         const int t2 = t / p.tilesW;
         const int th = t2 % p.tilesH;
         const int n = t2 / p.tilesH;
         const int hi0 = th * RO * S - 1, wi0 = tw * TW * S - 1;
         const bool live = t < p.nTiles;
-        const bool chans = 8 * fq < p.Cin;
         vmask = 0;
 #pragma unroll
         for (int m = 0; m < NPT; ++m) {
@@ -173,19 +175,23 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
             const bool ok = live & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);      // (no short circuit: no branches)
             vmask |= ok ? (1u << m) : 0u;
             const uint32_t off = (uint32_t)((((n * p.H + hi) * p.W + wi) * p.Cin + 8 * fq) * 2);        // < 2 GiB: checked by the host
-            xr[m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (ok & chans) ? off : 0x80000000u, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KA; ++ks)
+                xr[ks][m] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (ok & (32 * ks + 8 * fq < p.Cin)) ? off + 64 * ks : 0x80000000u, 0, 0);
         }
     };
 
-    u32x4 xa[NPT];
+    constexpr bool XPRE = KA == 1;                      // prefetch the next tile's x (register budget: only the one-K-step units)
+    u32x4 xa[KA][NPT];
     uint32_t vm;
-    load_x(tile, xa, vm);
+    if constexpr (XPRE) load_x(tile, xa, vm);
 
     while (tile < p.nTiles) {
         const int ntile = tile + nWavesAll;
-        u32x4 xb[NPT];
-        uint32_t vmn;
-        load_x(ntile, xb, vmn);                                                    // in flight during the whole tile
+        u32x4 xb[XPRE ? KA : 1][XPRE ? NPT : 1];
+        uint32_t vmn = 0;
+        if constexpr (XPRE) load_x(ntile, xb, vmn);                                // in flight during the whole tile
+        else load_x(tile, xa, vm);
 
         const int tw = tile % p.tilesW;
         const int t2 = tile / p.tilesW;
@@ -199,21 +205,48 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #pragma unroll
             for (int u = 0; u < R; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // weights from L2 (KA > 1): expand fragments one chunk ahead, projection fragments from the top of their chunk
+        u32x4 wen[WLDS ? 1 : KA][2], wpn[WLDS ? 1 : NRT];
+        auto load_we = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < KA; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    wen[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(wersrc, (uint32_t)(((32 * c + 16 * i + fr) * p.Kpad1 + 32 * ks + 8 * fq) * 2), 0, 0);
+        };
+        if constexpr (!WLDS) load_we(0);
+
 #pragma unroll 1
         for (int c = 0; c < p.nChunks; ++c) {
             // ---- S1: E chunk over the whole window ---------------------------------------------------------------------------------
             {
-                const frag we0 = *reinterpret_cast<const frag*>(we_rd + (32 * c) * PITCH);
-                const frag we1 = *reinterpret_cast<const frag*>(we_rd + (32 * c + 16) * PITCH);
+                frag we[KA][2];
+#pragma unroll
+                for (int ks = 0; ks < KA; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if constexpr (WLDS) we[ks][i] = *reinterpret_cast<const frag*>(we_rd + (32 * c + 16 * i) * PITCH);
+                        else we[ks][i] = __builtin_bit_cast(frag, wen[ks][i]);
+                    }
+                if constexpr (!WLDS) {                                             // next chunk's expand fragments + this chunk's projection
+                    load_we(c + 1 < p.nChunks ? c + 1 : c);                        // fragments: in flight under S1 / S2
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i)
+                        wpn[i] = __builtin_amdgcn_raw_buffer_load_b128(wprsrc, (uint32_t)(((16 * i + fr) * p.Kpad2 + 32 * c + 8 * fq) * 2), 0, 0);
+                }
                 const f32x4 se0 = *reinterpret_cast<const f32x4*>(BNs + 32 * c + 8 * fq);
                 const f32x4 se1 = *reinterpret_cast<const f32x4*>(BNs + 32 * c + 8 * fq + 4);
                 const f32x4 he0 = *reinterpret_cast<const f32x4*>(BNs + CmidP + 32 * c + 8 * fq);
                 const f32x4 he1 = *reinterpret_cast<const f32x4*>(BNs + CmidP + 32 * c + 8 * fq + 4);
 #pragma unroll
                 for (int m = 0; m < NPT; ++m) {
-                    const frag b = __builtin_bit_cast(frag, xa[m]);
-                    const f32x4 e0 = Mma<DT>::run(we0, b, (f32x4){0.f, 0.f, 0.f, 0.f});
-                    const f32x4 e1 = Mma<DT>::run(we1, b, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    f32x4 e0 = (f32x4){0.f, 0.f, 0.f, 0.f}, e1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KA; ++ks) {
+                        const frag b = __builtin_bit_cast(frag, xa[ks][m]);
+                        e0 = Mma<DT>::run(we[ks][0], b, e0);
+                        e1 = Mma<DT>::run(we[ks][1], b, e1);
+                    }
                     // BN as packed fma (v_pk_fma_f32); pixels outside the image must come out 0 (the depthwise pads the EXPANDED map)
                     f32x2 t[4];
                     t[0] = (f32x2){e0[0], e0[1]} * (f32x2){se0[0], se0[1]} + (f32x2){he0[0], he0[1]};
@@ -242,7 +275,23 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                     }
                     *reinterpret_cast<u32x4*>(const_cast<char*>(e_wr) + 16 * m * PITCH) = o;
                 }
+                // Schedule: the MFMAs of pixel block m + 1 go out with the BN / clamp / pack VALU work of block m (left alone the
+                // compiler issues all 2 KA NPT MFMAs first and the VALU work after them: the two pipes of the SIMD never overlap
+                // inside a wave, and with two waves per SIMD they rarely do across waves).
+                if constexpr (ACT == PCV_ACT_RELU || ACT == PCV_ACT_RELU6) {
+#pragma unroll
+                    for (int m = 0; m < NPT; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * KA, 0);
+                        if (m > 0) {
+                            __builtin_amdgcn_sched_group_barrier(0x002, 26, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x002, 26, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
             // ---- S2: depthwise 3x3 of the E chunk -> D chunk -------------------------------------------------------------------------
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -280,7 +329,10 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
             {
                 frag wp[NRT];
 #pragma unroll
-                for (int i = 0; i < NRT; ++i) wp[i] = *reinterpret_cast<const frag*>(wp_rd + ((c * NRT + i) * 16) * PITCH);
+                for (int i = 0; i < NRT; ++i) {
+                    if constexpr (WLDS) wp[i] = *reinterpret_cast<const frag*>(wp_rd + ((c * NRT + i) * 16) * PITCH);
+                    else wp[i] = __builtin_bit_cast(frag, wpn[i]);
+                }
 #pragma unroll
                 for (int u = 0; u < R; ++u) {
                     const frag b = *reinterpret_cast<const frag*>(d_rd + (16 * u) * PITCH);
@@ -331,9 +383,11 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
         }
 
         tile = ntile;
+        if constexpr (XPRE) {
 #pragma unroll
-        for (int m = 0; m < NPT; ++m) xa[m] = xb[m];
-        vm = vmn;
+            for (int m = 0; m < NPT; ++m) xa[0][m] = xb[0][m];
+            vm = vmn;
+        }
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }

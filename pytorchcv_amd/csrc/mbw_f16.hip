@@ -1,3 +1,4 @@
 // mbw_f16.hip - fp16 instantiations of the wave-private fused inverted-residual kernel
 #include "mbw_inst.hpp"
 MBW_SHAPES(MBW_DEFINE, PCV_F16)
+MBW2_SHAPES(MBW2_DEFINE, PCV_F16)

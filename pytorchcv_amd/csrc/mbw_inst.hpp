@@ -8,5 +8,12 @@
     X(DT, S, NRT, PCV_ACT_RELU6, 16) X(DT, S, NRT, PCV_ACT_RELU6, 8)
 #define MBW_SHAPES(X, DT) MBW_SHAPES3(X, DT, 1, 2) MBW_SHAPES3(X, DT, 1, 4) MBW_SHAPES3(X, DT, 2, 2) MBW_SHAPES3(X, DT, 2, 4)
 
+// two expand K steps (Cin <= 64), weights from L2: stride 1 only, 64 / 96 projected channels
+#define MBW2_SHAPES(X, DT) \
+    X(DT, 1, 4, -1, 16, 2) X(DT, 1, 4, -1, 8, 2) X(DT, 1, 4, PCV_ACT_RELU, 16, 2) X(DT, 1, 4, PCV_ACT_RELU, 8, 2) \
+    X(DT, 1, 4, PCV_ACT_RELU6, 16, 2) X(DT, 1, 4, PCV_ACT_RELU6, 8, 2)
+#define MBW2_DEFINE(DT, S, NRT, ACT, TW, KA) template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA>(const MbParams);
+#define MBW2_DECLARE(DT, S, NRT, ACT, TW, KA) extern template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA>(const MbParams);
+
 #define MBW_DEFINE(DT, S, NRT, ACT, TW) template __global__ void mbw_kernel<DT, S, NRT, ACT, TW>(const MbParams);
 #define MBW_DECLARE(DT, S, NRT, ACT, TW) extern template __global__ void mbw_kernel<DT, S, NRT, ACT, TW>(const MbParams);

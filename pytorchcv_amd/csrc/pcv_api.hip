@@ -18,6 +18,8 @@
 #include "mbw_inst.hpp"
 MBW_SHAPES(MBW_DECLARE, PCV_BF16)
 MBW_SHAPES(MBW_DECLARE, PCV_F16)
+MBW2_SHAPES(MBW2_DECLARE, PCV_BF16)
+MBW2_SHAPES(MBW2_DECLARE, PCV_F16)
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 #include "head_gemm.hpp"
@@ -494,21 +496,23 @@ static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
     return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
 }
 // wave-private variant (mbw.hpp): Cin <= 32, Cout <= 64
-struct MbwEntry { int dt, s, nrt, act, tw; mbconv_fn fn; };
-#define MBW_ROW(DT, S, NRT, ACT, TW) {DT, S, NRT, ACT, TW, mbw_kernel<DT, S, NRT, ACT, TW>},
-static const MbwEntry kMbw[] = {MBW_SHAPES(MBW_ROW, PCV_BF16) MBW_SHAPES(MBW_ROW, PCV_F16)};
+struct MbwEntry { int dt, s, nrt, act, tw, ka; mbconv_fn fn; };
+#define MBW_ROW(DT, S, NRT, ACT, TW) {DT, S, NRT, ACT, TW, 1, mbw_kernel<DT, S, NRT, ACT, TW>},
+#define MBW2_ROW(DT, S, NRT, ACT, TW, KA) {DT, S, NRT, ACT, TW, KA, mbw_kernel<DT, S, NRT, ACT, TW, KA>},
+static const MbwEntry kMbw[] = {MBW_SHAPES(MBW_ROW, PCV_BF16) MBW_SHAPES(MBW_ROW, PCV_F16) MBW2_SHAPES(MBW2_ROW, PCV_BF16)
+                                MBW2_SHAPES(MBW2_ROW, PCV_F16)};
 // act: PCV_ACT_RELU / PCV_ACT_RELU6 when both inner activations are that one, anything else = the launch-time codes
-static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw) {
+static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka) {
     if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
     for (const MbwEntry& e : kMbw)
-        if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw) return e.fn;
+        if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw && e.ka == ka) return e.fn;
     return nullptr;
 }
 static const int kMbwMaxLds = 160 * 1024;
 // waves per block (one block per CU): as many of 8 / 6 / 4 as the LDS holds beside the unit's weights; 0 = does not fit
-static int mbw_waves(int stride, int nrt, int nChunks, int tw) {
+static int mbw_waves(int stride, int nrt, int nChunks, int tw, int ka) {
     for (int nw = 8; nw >= 4; nw -= 2)
-        if (mbw_lds_layout(stride, nrt, nChunks, nw, tw).total <= kMbwMaxLds) return nw;
+        if (mbw_lds_layout(stride, nrt, nChunks, nw, tw, ka).total <= kMbwMaxLds) return nw;
     return 0;
 }
 static const int kMbMaxLds = 150 * 1024;
@@ -532,6 +536,15 @@ static int enable_mbconv(pcv_ctx* ctx) {
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
     return PCV_OK;
 }
+// Shapes the wave-private kernel (mbw.hpp) runs: an expand convolution with one K step (Cin <= 32: any stride, <= 64 projected
+// channels, weights in LDS) or two (Cin <= 64: stride 1, <= 64 projected channels, weights stay in L2).
+static bool mbw_shape(int Cin, int Cout, int stride, int H, int W, int* ka_out, int* nrt_out) {
+    const int ka = (Cin + 31) / 32, nrt = Cout <= 32 ? 2 : 4;
+    if (ka_out) *ka_out = ka;
+    if (nrt_out) *nrt_out = nrt;
+    if (H > 250 || W > 250 || Cout > 64) return false;
+    return ka == 1 || (ka == 2 && stride == 1 && nrt == 4);
+}
 // de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
 static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_desc& dd, const pcv_conv_desc& dp) {
     if ((de && desc_stale(*de)) || desc_stale(dd) || desc_stale(dp)) return kStaleDesc;
@@ -553,7 +566,7 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
     // measured (MobileNetV2, batch 512): the fused unit wins on the large maps (the expanded tensor is what costs) and loses on
     // 14x14 and below / wide projections, where the three separate launches are cheap and this kernel is VALU-bound
     // the wave-private kernel (mbw.hpp: at most 32 unit inputs, one expand K step) also takes 64 projected channels and 14x14 maps
-    const bool wave_tiles = de && de->Cin <= 32 && dd.H <= 250 && dd.W <= 250;
+    const bool wave_tiles = de && mbw_shape(de->Cin, dp.Cout, dd.stride_h, dd.H, dd.W, nullptr, nullptr);
     if (dp.Cout > (wave_tiles ? 64 : 32)) return "fused unit only pays for narrow projections";
     const int Ho = (dd.H - 1) / dd.stride_h + 1, Wo = (dd.W - 1) / dd.stride_w + 1;
     if (dp.N != dd.N || dp.H != Ho || dp.W != Wo) return "shapes do not chain";
@@ -567,7 +580,9 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
         if (ka > 3) return "expand stage input wider than 96 channels";
     }
     int nbuf = 0;
-    if (mbconv_plan(dd.stride_h, de != nullptr, ka, (Cmid + 31) / 32, (dp.Cout + 31) / 32 * 2, &nbuf).total > kMbMaxLds)
+    if (wave_tiles) {
+        if (mbw_waves(dd.stride_h, dp.Cout <= 32 ? 2 : 4, (Cmid + 31) / 32, 16, ka) == 0) return "tiles do not fit the LDS budget";
+    } else if (mbconv_plan(dd.stride_h, de != nullptr, ka, (Cmid + 31) / 32, (dp.Cout + 31) / 32 * 2, &nbuf).total > kMbMaxLds)
         return "weights + tiles do not fit the LDS budget";
     const long cin = de ? de->Cin : Cmid;
     if ((long)dd.N * dd.H * dd.W * cin * 2 >= (1L << 31) || (long)dd.N * Ho * Wo * dp.Cout * 2 >= (1L << 31)) return "tensor exceeds the 2 GiB window";
@@ -1593,25 +1608,27 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     p.act_e = d_exp ? d_exp->act : 0; p.act_d = d_dw->act; p.act_p = d_proj->act; p.post = d_proj->post_act;
     if (p.nRowT > 6 || (d_exp && p.Kpad1 < 32 * p.ka) || p.Kpad2 < 32 * p.nChunks)
         return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
-    // wave-private tiles (mbw.hpp) where the unit qualifies: one K step of expand input, at most 64 projected channels
-    if (ctx->use_mbw && d_exp && p.Cin <= 32 && p.nRowT <= 4 && p.H <= 250 && p.W <= 250) {
-        const int nrt = p.nRowT <= 2 ? 2 : 4;
+    // wave-private tiles (mbw.hpp) where the unit qualifies; pcv_set_tuning("mbw", 0) sends the shapes BOTH kernels cover to mbconv.hpp
+    int kaw = 0, nrt = 0;
+    const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt);
+    const bool block_shape = p.Cout <= 32 && p.Wo >= 24;
+    if (wave_shape && (ctx->use_mbw || !block_shape)) {
         // pixel-block shape: 1 x 16 or 2 x 8 outputs, whichever covers the map with less expand work (window blocks x tiles)
         const int nblk = S == 1 ? 4 : 2;
         auto tiles_of = [&](int tw) { return (long)((p.Ho + nblk * (16 / tw) - 1) / (nblk * (16 / tw))) * ((p.Wo + tw - 1) / tw); };
         int tw = mbw_npt(S, 8) * tiles_of(8) < mbw_npt(S, 16) * tiles_of(16) ? 8 : 16;
         if (ctx->use_mbw == 8 || ctx->use_mbw == 16) tw = ctx->use_mbw;
-        const int nw = mbw_waves(S, nrt, p.nChunks, tw);
+        const int nw = mbw_waves(S, nrt, p.nChunks, tw, kaw);
         if (nw > 0) {
             const int RO = nblk * (16 / tw);
             p.tilesH = (p.Ho + RO - 1) / RO; p.tilesW = (p.Wo + tw - 1) / tw;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
-            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw, tw);
+            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw, tw, kaw);
             const long want = (nT + nw - 1) / nw;
             const unsigned gridw = (unsigned)std::min<long>(want, (long)block_slots(ctx, 1));
-            mbconv_fn fnw = pick_mbw(d_dw->dtype, S, nrt, p.act_e == p.act_d ? p.act_e : -1, tw);
+            mbconv_fn fnw = pick_mbw(d_dw->dtype, S, nrt, p.act_e == p.act_d ? p.act_e : -1, tw, kaw);
             if (!fnw) return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: no kernel instantiation");
             hipLaunchKernelGGL(fnw, dim3(gridw), dim3(64 * nw), wl.total, (hipStream_t)stream, p);
             HIP_TRY(ctx, hipGetLastError());

@@ -312,6 +312,7 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
     (2, 33, 47, 40, True, 24, 1, "relu"), (2, 56, 56, 40, True, 32, 2, "relu6"), (1, 28, 28, 96, True, 32, 1, None),
     (2, 61, 45, 32, True, 32, 1, "relu6"), (1, 112, 112, 16, True, 24, 2, "relu6"), (5, 56, 56, 24, True, 24, 1, "relu6"),
     (3, 28, 28, 32, True, 64, 2, "relu6"), (2, 14, 14, 32, True, 64, 1, "relu6"),
+    (5, 14, 14, 64, True, 64, 1, "relu6"), (3, 28, 25, 40, True, 48, 1, "relu"), (2, 17, 14, 64, True, 56, 1, "hswish"),
 ]
 
 
