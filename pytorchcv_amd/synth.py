@@ -40,8 +40,11 @@ def name_stream(name: str) -> int:
     return zlib.crc32(name.encode("utf-8")) & 0xFFFFFFFF
 
 
-def _raw(seed: int, stream: int, lane: int, n: int) -> np.ndarray:
-    idx = np.arange(n, dtype=np.uint64)
+_CHUNK = 1 << 16        # elements per pass: the integer temporaries of a chunk (512 KB each) stay in cache and are recycled by the allocator
+
+
+def _raw(seed: int, stream: int, lane: int, n: int, start: int = 0) -> np.ndarray:
+    idx = np.arange(start, start + n, dtype=np.uint64)
     with np.errstate(over='ignore'):
         key = (np.uint64(seed) * np.uint64(0xD1342543DE82EF95)
                + np.uint64(stream) * np.uint64(0xA0761D6478BD642F)
@@ -51,9 +54,25 @@ def _raw(seed: int, stream: int, lane: int, n: int) -> np.ndarray:
 
 
 def hash_uniform(seed: int, stream: int, n: int, lane: int = 0) -> np.ndarray:
-    """n float64 values in [0, 1) with 24 significant bits (exact in fp32)."""
-    z = _raw(seed, stream, lane, n)
-    return (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+    """n float64 values in [0, 1) with 24 significant bits (exact in fp32). Evaluated chunk by chunk (same values: element i
+    depends on (seed, stream, lane, i) only) - a 100 M-element classifier matrix in one piece streams ~20 GB of temporaries."""
+    out = np.empty(n, dtype=np.float64)
+    for a in range(0, n, _CHUNK):
+        m = min(_CHUNK, n - a)
+        z = _raw(seed, stream, lane, m, start=a)
+        out[a:a + m] = (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+    return out
+
+
+def _uniform_pm_f32(seed: int, stream: int, n: int, bound: float) -> np.ndarray:
+    """float32((2 u - 1) * bound) for u = hash_uniform(seed, stream, n), produced chunk by chunk straight into the fp32 array (the
+    same values as the float64 expression followed by astype: elementwise; no gigabyte-sized float64 intermediates)."""
+    out = np.empty(n, dtype=np.float32)
+    for a in range(0, n, _CHUNK):
+        m = min(_CHUNK, n - a)
+        u = (_raw(seed, stream, 0, m, start=a) >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+        out[a:a + m] = ((u * 2.0 - 1.0) * bound).astype(np.float32)
+    return out
 
 
 def hash_normal(seed: int, stream: int, n: int, lane: int = 0) -> np.ndarray:
@@ -112,10 +131,10 @@ def synth_state_dict(template: dict, seed: int = 1234, calib: dict | None = None
         elif leaf == "weight" and len(shape) == 4:
             fan_in = shape[1] * shape[2] * shape[3]
             bound = float(np.sqrt(np.float64(6.0) / np.float64(fan_in)))
-            v = (hash_uniform(seed, st, n) * 2.0 - 1.0) * bound
+            v = _uniform_pm_f32(seed, st, n, bound)
         elif leaf == "weight" and len(shape) == 2:
             bound = float(1.0 / np.sqrt(np.float64(shape[1])))
-            v = (hash_uniform(seed, st, n) * 2.0 - 1.0) * bound
+            v = _uniform_pm_f32(seed, st, n, bound)
         elif leaf == "bias":
             v = (hash_uniform(seed, st, n) * 2.0 - 1.0) * 0.1
         else:

@@ -108,10 +108,19 @@ def model_calib(name):
         return {k: tuple(v) for k, v in json.load(f).items()}
 
 
+_state_cache = {}       # name -> state dict; the integer-hash generator is bit-stable but slow (VGG-11: 133 M values, ~1 min)
+
+
 def model_state(name, template=None):
-    if template is None:
-        template = template_from_manifest(model_manifest(name)["keys"])
-    return synth_state_dict(template, seed=1234, calib=model_calib(name))
+    """The fixture state dict of a golden model (same values whichever template - the manifest's or a live net's - names the keys).
+    Cached per process (last three models); callers load it into modules, nobody writes into it."""
+    if name not in _state_cache:
+        if template is None:
+            template = template_from_manifest(model_manifest(name)["keys"])
+        while len(_state_cache) >= 3:
+            _state_cache.pop(next(iter(_state_cache)))
+        _state_cache[name] = synth_state_dict(template, seed=1234, calib=model_calib(name))
+    return dict(_state_cache[name])
 
 
 def model_golden(name):
