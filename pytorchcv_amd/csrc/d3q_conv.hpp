@@ -93,7 +93,10 @@ struct D3Params {
 
 // WC x WP: compute-wave grid (channels x pixels), 8 waves. CBW / PBW: 16-row blocks per wave (channels / pixels).
 // KS: K-halves (32 elements each) per read / MFMA section.
-template <int WC, int WP, int CBW, int PBW, int KS> struct D3Cfg {
+// ONE: the 1x1 / stride 1 mode for K-heavy layers (ResNeXt-101 stage 3: 512 <-> 1024 channels at 14x14): every K-step is its own
+// group - the activation tile of K-step s is the same pixel rows, 64-channel slice s - so the B ring is three slots deep like the A
+// ring (tiles of K-step s + 2 are issued during K-step s) and the compute waves always take the unmasked centre-column path.
+template <int WC, int WP, int CBW, int PBW, int KS, bool ONE = false> struct D3Cfg {
     static constexpr int NLOAD = 4;                          // loader waves (waves 8..11)
     static constexpr int THREADS = 64 * (8 + NLOAD);
     static constexpr int BM = 16 * CBW * WC;                 // channel rows per block tile
@@ -107,7 +110,8 @@ template <int WC, int WP, int CBW, int PBW, int KS> struct D3Cfg {
     static constexpr int ASZ = BM * 128;                     // bytes of one A slot
     static constexpr int BSZ = NPB * 1024;                   // bytes of one B slot
     static constexpr int NSA = 3;
-    static constexpr int ZOFF = NSA * ASZ + 2 * BSZ;         // 128 zero bytes: the row a horizontally padded tap reads
+    static constexpr int NSB = ONE ? 3 : 2;
+    static constexpr int ZOFF = NSA * ASZ + NSB * BSZ;       // 128 zero bytes: the row a horizontally padded tap reads
     static constexpr int DUMP = ZOFF + 128;                  // 1 KB: where the (NLOAD XLW - NPB) surplus pieces of a group land (every
                                                              // loader issues the same number of pieces: the vmcnt counts are constants)
     static constexpr int LDS = DUMP + 1024;
@@ -140,9 +144,9 @@ __device__ __forceinline__ void d3q_sync() {
 }
 
 // ---- loader wave lw (0..3): every LDS-DMA piece of the block ------------------------------------------------------------------------
-template <int DT, int WC, int WP, int CBW, int PBW, int KS>
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, bool ONE>
 __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const int lw) {
-    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
+    typedef D3Cfg<WC, WP, CBW, PBW, KS, ONE> G;
     constexpr int BM = G::BM, BP = G::BP, WLW = G::WLW, XLW = G::XLW, NSA = G::NSA, NL = G::NLOAD;
     typedef __attribute__((address_space(3))) char lds_char;
     const int lane = threadIdx.x & 63;
@@ -152,7 +156,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     const D3Tiles T = d3q_tiles(p);
     if (T.nMine == 0) return;
     const int nk = p.nk;
-    const int K_total = T.nMine * nk, G_total = T.nMine * (nk / 3);
+    const int K_total = T.nMine * nk, G_total = ONE ? K_total : T.nMine * (nk / 3);
 
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     // Activations: the descriptor's base sits one image row BELOW x, so that the (wave-uniform, unsigned) scalar offset of a
@@ -160,7 +164,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     // of any pixel plus the largest scalar offset (whether or not the range check adds the scalar offset, a valid lane passes
     // it); a row that must read as zeros gets the offset 2^31, beyond num_records either way (the host keeps
     // x_bytes + 2 rows below 2^31).
-    const uint32_t rowBytes = (uint32_t)(p.W * p.Cin * 2);
+    const uint32_t rowBytes = ONE ? 0u : (uint32_t)(p.W * p.Cin * 2);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(p.x)) - rowBytes, 0, p.x_bytes + 2u * rowBytes, 0x00020000);
 
@@ -206,7 +210,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
                 const uint32_t n = fastdiv((uint32_t)m, p.div_hw);
                 const uint32_t ho = fastdiv((uint32_t)m - n * (uint32_t)p.HW, p.div_w);
                 off = (uint32_t)((m * p.Cin + cs * 8) * 2);
-                vm = (ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u);
+                vm = ONE ? 7u : ((ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u));
             }
             pbv[j] = off;
             vmask[j / 10] |= vm << (3 * (j % 10));
@@ -214,7 +218,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     };
     auto dma_b = [&](auto J0c, auto J1c) __attribute__((always_inline)) {                // pieces [J0, J1) of the group
         constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
-        const uint32_t soff = (uint32_t)(lb_r * p.W * p.Cin + lb_c * 64) * 2u;
+        const uint32_t soff = ONE ? (uint32_t)(lb_c * 128) : (uint32_t)(lb_r * p.W * p.Cin + lb_c * 64) * 2u;
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
             const uint32_t dst = lds0 + (uint32_t)(NL * j + lw < G::NPB ? NSA * G::ASZ + lb_slot * G::BSZ + (NL * j + lw) * 1024 : G::DUMP);
@@ -225,10 +229,10 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     };
     auto advance_b = [&]() __attribute__((always_inline)) {   // group order inside a tile: (r, c), c fastest
         ++lb_g;
-        lb_slot ^= 1;
+        lb_slot = lb_slot + 1 == G::NSB ? 0 : lb_slot + 1;
         if (++lb_c == p.slices) {
             lb_c = 0;
-            if (++lb_r == 3) {
+            if (ONE || ++lb_r == 3) {
                 lb_r = 0;
                 lb_tile += T.tstride;
                 if (lb_tile < T.tend) setup_b(lb_tile);
@@ -253,6 +257,10 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     if (K_total > 1) {
         dma_a(C0{}, CAN{});
         advance_a();
+        if constexpr (ONE) {                                    // 1x1: the activation tile of K-step 1 too
+            dma_b(C0{}, CBN{});
+            advance_b();
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -280,18 +288,42 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         d3q_sync();
     };
-    for (int s = 0; s < K_total; s += 3) {
-        kstep(std::integral_constant<int, 0>{});
-        kstep(std::integral_constant<int, 1>{});
-        kstep(std::integral_constant<int, 2>{});
+    if constexpr (!ONE) {
+        for (int s = 0; s < K_total; s += 3) {
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+        }
+    } else {
+        // 1x1: K-step s issues the weight AND the activation tile of K-step s + 2, half of each per half K-step; before its last
+        // barrier everything issued before this K-step (both tiles of K-step s + 1) has landed.
+        for (int s = 0; s < K_total; ++s) {
+            const bool moreA = la_g < K_total, moreB = lb_g < G_total;          // (always equal: one group per K-step)
+            if (moreB) dma_b(C0{}, CB0{});
+            if (moreA) dma_a(C0{}, CA0{});
+            d3q_sync();
+            if constexpr (KS == 1) d3q_sync();
+            if (moreB) {
+                dma_b(CB0{}, CBN{});
+                advance_b();
+            }
+            if (moreA) {
+                dma_a(CA0{}, CAN{});
+                advance_a();
+            }
+            if constexpr (KS == 1) d3q_sync();
+            if (moreA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WLW + XLW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            d3q_sync();
+        }
     }
 }
 
 // ---- compute waves: the whole persistent loop of one group (GRP 0: waves 0-3, GRP 1: waves 4-7, one barrier interval behind). ------
 // The two instantiations are separate straight-line loop nests (no per-interval group branches for the register allocator to join).
-template <int DT, int WC, int WP, int CBW, int PBW, int KS, int GRP>
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, int GRP, bool ONE>
 __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const int wave) {
-    typedef D3Cfg<WC, WP, CBW, PBW, KS> G;
+    typedef D3Cfg<WC, WP, CBW, PBW, KS, ONE> G;
     constexpr int BM = G::BM, BP = G::BP, NSA = G::NSA;
     typedef typename Mma<DT>::frag frag;
 
@@ -427,7 +459,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
     };
 
     zero_acc();
-    setup_masks(T.tile0);
+    if constexpr (!ONE) setup_masks(T.tile0);
     d3q_sync();                                                // the loaders' prologue: K-steps 0 and 1, group 0, the zero row
 
     int sa = 0, sb = 0, k = 0, cur_tile = T.tile0, ep_tile = T.tile0;
@@ -444,11 +476,13 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         if constexpr (GRP == 1) {
             if (s > 0) mfmas();
         }
-        if constexpr (Q == 0) {                               // a tile ends behind q = 2 (nk is a multiple of 3)
+        if constexpr (ONE || Q == 0) {                        // a tile ends behind q = 2 (nk is a multiple of 3); 1x1: behind any K-step
             if (ep) {
                 epilogue(ep_tile);
                 zero_acc();
-                if (s < K_total) setup_masks(cur_tile);
+                if constexpr (!ONE) {
+                    if (s < K_total) setup_masks(cur_tile);
+                }
             }
             if (s == K_total) return true;
         }
@@ -492,16 +526,22 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
             cur_tile += T.tstride;
         }
         sa = sa + 1 == NSA ? 0 : sa + 1;
-        if constexpr (Q == 2) sb ^= 1;
+        if constexpr (ONE) sb = sb + 1 == G::NSB ? 0 : sb + 1;
+        else if constexpr (Q == 2) sb ^= 1;
         D3_STAMP(7);
         d3q_sync();
         D3_STAMP(8);
         return false;
     };
-    for (int s = 0;; s += 3) {
-        if (kstep(s, std::integral_constant<int, 0>{})) break;
-        if (kstep(s + 1, std::integral_constant<int, 1>{})) break;
-        if (kstep(s + 2, std::integral_constant<int, 2>{})) break;
+    if constexpr (ONE) {
+        for (int s = 0;; ++s)
+            if (kstep(s, std::integral_constant<int, 1>{})) break;        // the unmasked centre column: tile row u holds pixel P0 + u - 1
+    } else {
+        for (int s = 0;; s += 3) {
+            if (kstep(s, std::integral_constant<int, 0>{})) break;
+            if (kstep(s + 1, std::integral_constant<int, 1>{})) break;
+            if (kstep(s + 2, std::integral_constant<int, 2>{})) break;
+        }
     }
 #ifdef D3X3_STAMPS
     if (p.dbg != nullptr && blockIdx.x == 16) p.dbg[wave * 64 + lane] = (uint32_t)stamps;
@@ -509,14 +549,14 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int DT, int WC, int WP, int CBW, int PBW, int KS>
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, bool ONE = false>
 __global__ __launch_bounds__(768, 3) void d3q_kernel(const D3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // compute waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically), loader w + 8 joins them
-    if (wave < 4) d3q_body<DT, WC, WP, CBW, PBW, KS, 0>(p, smem, wave);
-    else if (wave < 8) d3q_body<DT, WC, WP, CBW, PBW, KS, 1>(p, smem, wave);
-    else d3q_loader<DT, WC, WP, CBW, PBW, KS>(p, smem, wave - 8);
+    if (wave < 4) d3q_body<DT, WC, WP, CBW, PBW, KS, 0, ONE>(p, smem, wave);
+    else if (wave < 8) d3q_body<DT, WC, WP, CBW, PBW, KS, 1, ONE>(p, smem, wave);
+    else d3q_loader<DT, WC, WP, CBW, PBW, KS, ONE>(p, smem, wave - 8);
 #endif  // __HIP_DEVICE_COMPILE__
 }

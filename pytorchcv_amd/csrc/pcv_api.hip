@@ -30,6 +30,8 @@ IGEMM_INSTANCES(IGEMM_DECLARE, PCV_F16)
 IGEMM_INSTANCES_SAMETYPE(IGEMM_DECLARE, PCV_F32)
 D3Q_SHAPES(D3Q_DECLARE, PCV_BF16)
 D3Q_SHAPES(D3Q_DECLARE, PCV_F16)
+D3Q1_SHAPES(D3Q1_DECLARE, PCV_BF16)
+D3Q1_SHAPES(D3Q1_DECLARE, PCV_F16)
 
 struct pcv_ctx {
     int device = 0;
@@ -39,6 +41,7 @@ struct pcv_ctx {
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
     int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp; 8 / 16: force that pixel-block width); 0: mbconv.hpp
+    int use_d1x1 = -1;          // K-heavy 1x1 layers on d3q_kernel's 1x1 mode: -1 = pick_d1x1, 0 = never, n > 0 = force shape n - 1 where eligible
     int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
@@ -359,11 +362,31 @@ struct D3Shape { int BM, BP, lds; const void* fn[2]; };       // fn[0] bf16, fn[
       reinterpret_cast<const void*>(d3q_kernel<PCV_F16, WC, WP, CBW, PBW, KS>)}},
 static const D3Shape kD3[] = {D3Q_SHAPES(D3Q_ROW, 0)};
 static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
+// the same kernel in its 1x1 mode (K-heavy pointwise layers)
+#define D3Q1_ROW(DT, WC, WP, CBW, PBW, KS)                                                                                     \
+    {D3Cfg<WC, WP, CBW, PBW, KS, true>::BM, D3Cfg<WC, WP, CBW, PBW, KS, true>::BP, D3Cfg<WC, WP, CBW, PBW, KS, true>::LDS,      \
+     {reinterpret_cast<const void*>(d3q_kernel<PCV_BF16, WC, WP, CBW, PBW, KS, true>),                                        \
+      reinterpret_cast<const void*>(d3q_kernel<PCV_F16, WC, WP, CBW, PBW, KS, true>)}},
+static const D3Shape kD1[] = {D3Q1_SHAPES(D3Q1_ROW, 0)};
+static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
+    for (int i = 0; i < kD1Count; ++i)
+        for (int t = 0; t < 2; ++t)
+            HIP_TRY(ctx, hipFuncSetAttribute(kD1[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD1[i].lds));
     return PCV_OK;
+}
+// 1x1 mode: which pointwise layers go to the 8 + 4-wave kernel: K >= 256 and >= 128 output channels (the short-K layers keep the
+// 4-wave kernel; where a fused pair applies the caller takes that first). Measured at batch 256 (us, generic -> this kernel):
+// 512->256 @28x28 106 -> 90, 512->1024 + skip @14x14 93 -> 85, 256->1024 + skip 69 -> 60, 1024->512 74 -> 72, 2048->512 @7x7 43 -> 39;
+// the 256 x 112 tile is 1-3 % ahead of 128 x 224 wherever the channel count fills it.
+static int pick_d1x1(long long M, int Cout, int Cin, long long slots) {
+    if (Cin < 256 || Cout < 128) return -1;
+    const int shape = Cout % 256 == 0 ? 1 : 0;
+    const long long tiles = (long long)((Cout + kD1[shape].BM - 1) / kD1[shape].BM) * ((M + kD1[shape].BP - 1) / kD1[shape].BP);
+    return tiles * 2 >= slots ? shape : -1;                      // too few tiles to fill the chip with one block per CU: 4-wave kernel
 }
 // Tile shape for M pixels x Cout channels on `slots` CUs (one block each). With the activation tile staged once per filter row
 // the bytes a K-step pulls through L2 are BM x 128 (weights) + BP x 128 / 3 (activations): wide pixel tiles with no more channel
@@ -676,6 +699,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "head") ctx->use_head = value;
+    else if (k == "d1x1") ctx->use_d1x1 = value;
     else if (k == "mbw") ctx->use_mbw = value;
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
@@ -964,6 +988,47 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         q.nTiles = (int)nT;
         q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
         long long nb = slots < nT ? slots : nT;
+        nb = (nb + 7) / 8 * 8;
+        void* args[] = {&q};
+        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));
+        return PCV_OK;
+    }
+
+    // ---- K-heavy 1x1 / stride 1, 16 bit: d3q_kernel's 1x1 mode ---------------------------------------------------------------------
+    int d1shape = -1;
+    if (ctx->use_d1x1 != 0 && !gate && !P.pair && d->dtype != PCV_F32 && d->out_dtype == d->dtype && d->kh == 1 && d->kw == 1 &&
+        d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
+        cpitch == d->Cin && wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && d->act <= PCV_ACT_RELU6 &&
+        d->post_act <= PCV_ACT_RELU6 && scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        d1shape = ctx->use_d1x1 > 0 ? std::min(ctx->use_d1x1 - 1, kD1Count - 1)
+                                    : pick_d1x1((long long)M64, d->Cout, d->Cin, (long long)block_slots(ctx, 1));
+    }
+    if (d1shape >= 0) {
+        const int ypitch1 = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+        const unsigned long long ybytes1 = ((M64 - 1) * (unsigned long long)ypitch1 + d->Cout) * 2ull;
+        if (ypitch1 < d->Cout || (ypitch1 * 2) % 16 != 0)
+            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
+        if (ybytes1 >= 0x80000000ull)
+            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+        const D3Shape& S = kD1[d1shape];
+        D3Params q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
+        q.scale = scale; q.shift = shift;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes1;
+        q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
+        q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch1;
+        q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.HW = d->H * d->W;
+        q.div_hw = make_fastdiv((uint32_t)q.HW);
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.nk = d->Cin / 64; q.slices = q.nk; q.Kpad = P.Kpad;
+        q.act = d->act; q.post_act = d->post_act;
+        q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
+        const long long nT = ((long long)((M64 + S.BP - 1) / S.BP)) * q.nChTiles;
+        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+        q.nTiles = (int)nT;
+        const long long slots1 = block_slots(ctx, 1);
+        long long nb = slots1 < nT ? slots1 : nT;
         nb = (nb + 7) / 8 * 8;
         void* args[] = {&q};
         HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));

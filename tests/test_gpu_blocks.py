@@ -554,3 +554,37 @@ def test_stem_full_batch_is_repeatable(kind, cuda_device):
         for rep in range(10):
             y = blk(engine.from_nchw(x, "bf16", stem=True)).t
             assert torch.equal(y, want), "pass {}: {} images differ".format(rep, int((y != want).flatten(1).any(1).sum()))
+
+
+_D1_SHAPES = [  # (N, Cin, Cout, H, W, residual): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
+    (16, 1024, 512, 14, 14, False), (16, 512, 1024, 14, 14, True), (9, 2048, 512, 7, 7, False), (5, 512, 2048, 7, 7, True),
+    (3, 576, 136, 13, 11, False), (2, 64, 256, 20, 20, True), (1, 192, 72, 5, 9, False),
+]
+
+
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _D1_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D1_SHAPES])
+def test_conv1x1_eight_wave_mode_equals_generic(shape, dtype, grid, cuda_device):
+    """The 1x1 mode of the 8 + 4-wave kernel (both tile shapes forced, and the automatic choice) is bit-identical to the generic
+    implicit-GEMM kernel (same K order, same fp32 accumulation chain per output), which the oracle tests above pin."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block
+    N, C, Cout, H, W, use_res = shape
+    blk = conv1x1_block(in_channels=C, out_channels=Cout).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=83))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=29)
+    res = util.synth_input(N, Cout, H, W, seed=30) if use_res else None
+    outs = {}
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        for name, sw in (("generic", 0), ("auto", -1), ("128x224", 1), ("256x112", 2)):
+            with util.tuning(max_blocks=grid, d1x1=sw):
+                outs[name] = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None).t.clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs["generic"].float()).all())
+    for name in ("auto", "128x224", "256x112"):
+        assert torch.equal(outs[name], outs["generic"]), "{}: {} elements differ".format(name, int((outs[name] != outs["generic"]).sum()))
