@@ -208,15 +208,29 @@ def rocprof_class_us(workload, klass):
     import glob
     names = {"dense3x3": ("d3q_kernel", "false, 9>"), "depthwise": ("dwconv_kernel", "dwconv5_kernel"),
              "grouped3x3": ("gconv3x3_kernel",), "fused_unit": ("mbw_kernel", "mbconv_kernel")}.get(klass)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_{}_*kernel_stats*.csv".format(workload.replace("_bs", "_bs")))))
-    if not names or not files:
+    if not names:
+        return None, None
+    # preferred: one full-batch forward in dispatch order (tests/tools/trace_summary.py of the same rocprofv3 run) - the --stats
+    # table also counts the 8-image warm-up forward's launches
+    traces = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_{}_*per_launch*.txt".format(workload))))
+    if traces:
+        tot = calls = 0
+        with open(traces[-1]) as f:
+            for line in f:
+                if any(n in line for n in names) and ", true>(D3Params)" not in line and line.rstrip().endswith("us"):
+                    tot += float(line.split()[-2])
+                    calls += 1
+        if calls:
+            return round(tot / calls, 2), os.path.relpath(traces[-1], ROOT)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_{}_*kernel_stats*.csv".format(workload))))
+    if not files:
         return None, None
     tot = calls = 0
     with open(files[-1]) as f:
         for row in csv.DictReader(f):
-            if any(n in row["Name"] for n in names):
+            if any(n in row["Name"] for n in names) and ", true>(D3Params)" not in row["Name"]:      # (d3q's 1x1 mode is another class)
                 tot += int(row["TotalDurationNs"])
-                calls += int(row["Calls"])
+                calls += 1 * int(row["Calls"])
     return (round(tot / calls / 1e3, 2), os.path.relpath(files[-1], ROOT)) if calls else (None, None)
 
 
@@ -365,7 +379,7 @@ def main():
                         avg_launch_us=round(1e3 * s["avg_ms"], 2),
                         avg_launch_us_source="live: HIP events around every eager launch of the class on the launch stream (this run)",
                         rocprof_avg_launch_us=rp_us,
-                        rocprof_source=("committed rocprofv3 --kernel-trace --stats of this command with --lanes 1: " + rp_file) if rp_file else None,
+                        rocprof_source=("committed rocprofv3 --kernel-trace of this command with --lanes 1 (one full-batch forward): " + rp_file) if rp_file else None,
                         algorithmic_per_launch=(round(s["flops_per_launch"] / 1e9, 3) if bound == "mfma"
                                                 else round(s["bytes_per_launch"] / 1e6, 3)),
                         algorithmic_unit="GFLOP" if bound == "mfma" else "MB",

@@ -15,7 +15,7 @@ def pick(name, klass):
     if klass == "grouped3x3":
         return "gconv3x3_kernel" in name
     if klass == "dense3x3":
-        return "d3q_kernel" in name or ("igemm_conv_kernel" in name and name.rstrip().rstrip(")").split("(")[0].rstrip().endswith(", 9>"))
+        return ("d3q_kernel" in name and ", true>(D3Params)" not in name) or ("igemm_conv_kernel" in name and name.rstrip().rstrip(")").split("(")[0].rstrip().endswith(", 9>"))
     if klass == "fused_unit":
         return "mbw_kernel" in name or "mbconv_kernel" in name
     if klass == "depthwise":
