@@ -40,10 +40,12 @@ def test_registry_model_runs_and_matches_oracle(name, size, check, cuda_device):
     if check:
         ref = refnet.forward(name, {k: v.float() for k, v in sd.items()}, x)
         err = float((y - ref).abs().max())
-        # uncalibrated random weights let activations grow to 1e2..1e3 and make the nets ill-conditioned: the CPU oracle's own
-        # fp32-vs-fp64 distance on efficientnet_b3b is 6e-3 of max|logit|, so 5e-3 is what fp32 can be held to here (a wrong
-        # padding or channel order shows up as O(1) relative error)
-        assert err <= 5e-3 * max(1.0, float(ref.abs().max())), (name, err)
+        # fp32 path vs the fp32 oracle, relative to max|logit| (uncalibrated random weights: logits reach 1e1..4e3). Measured
+        # (tests/tools/registry_errs.py): 3e-7 .. 7e-6 on every net but the two below, so 2e-5 is the bound - a wrong padding, channel
+        # order or rounding point is O(1) .. 1e-3 off. efficientnet_b3b with these weights is ill-conditioned (the CPU oracle's OWN
+        # fp32-vs-fp64 distance is 6e-3 of max|logit|; measured here 1.7e-3), sepreresnet50b measures 5e-5.
+        bound = {"efficientnet_b3b": 5e-3, "sepreresnet50b": 3e-4, "efficientnet_b1": 5e-5, "mobilenetv3_large_w5d4": 3e-5}.get(name, 2e-5)
+        assert err <= bound * max(1.0, float(ref.abs().max())), (name, err / max(1.0, float(ref.abs().max())))
 
 
 def test_odd_channel_blocks_are_padded_not_refused(cuda_device):
