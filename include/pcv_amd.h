@@ -143,6 +143,15 @@ int pcv_fc_f32(pcv_ctx* ctx, const float* in, const float* w, const float* b, fl
 int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, int ceil_mode);
 int pcv_conv2d_maxpool_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
                              const float* shift, void* y, int k, int s, int p, int ceil_mode, void* stream);
+
+/* The stem convolution (+ BN + activation, + the MaxPool2d(3, 2, 1) behind it when `pool`) reading the caller's fp32 NCHW image
+ * itself: what `ResNet.forward` hands to `features.init_block` (reference resnet.py:333-334, mobilenetv2.py:152-153) without the
+ * pcv_nchw_to_nhwc pass in front. `d` describes the convolution exactly as for pcv_conv2d_fused on the padded NHWC4 view
+ * (Cin <= 3, x_cpitch 4, even x_wpitch); x_nchw is [N, Cin, H, W] fp32 with W a multiple of 4. Results are bit-identical to
+ * pcv_nchw_to_nhwc + pcv_conv2d_fused / pcv_conv2d_maxpool_fused. */
+int pcv_conv2d_nchw_stem_supported(const pcv_conv_desc* d, int pool);
+int pcv_conv2d_nchw_stem_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const float* x_nchw, const void* packed, const float* scale,
+                               const float* shift, void* y, int pool, void* stream);
 /* Depthwise direct convolution, fused epilogue (same contract). */
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed,
                        const float* scale, const float* shift, const void* residual, void* y, void* stream);

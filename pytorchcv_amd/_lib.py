@@ -72,6 +72,8 @@ _SIGS = {
     "pcv_fc_f32": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
     "pcv_conv2d_maxpool_supported": (_I, [ctypes.POINTER(ConvDesc), _I, _I, _I, _I]),
     "pcv_conv2d_maxpool_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP]),
+    "pcv_conv2d_nchw_stem_supported": (_I, [ctypes.POINTER(ConvDesc), _I]),
+    "pcv_conv2d_nchw_stem_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "pcv_conv1x1_pair_supported": (_I, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc)]),
     "pcv_conv1x1_pair_fused": (_I, [_VP, ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                     _VP, _VP, _VP, _VP]),

@@ -412,6 +412,12 @@ static int enable_stem(pcv_ctx* ctx) {
     const void* pooled[2] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, true>),
                              reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, true>)};
     for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipFuncSetAttribute(pooled[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
+    const void* from_nchw[4] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, false, true>),
+                                reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, false, true>),
+                                reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, true, true>),
+                                reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, true, true>)};
+    for (int i = 0; i < 4; ++i)
+        HIP_TRY(ctx, hipFuncSetAttribute(from_nchw[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds + kStemStageBytes));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
         int nb = 0;
@@ -869,8 +875,10 @@ static int pool_out(int in, int k, int s, int p, int ceil_mode);
 static void launch_se_fc(const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act, hipStream_t st);
 
 // pool: the MaxPool2d(3, 2, 1) of the init block fused behind the stem convolution (pcv_conv2d_maxpool_fused)
+// x_nchw: the stem convolution reads the fp32 NCHW image itself (pcv_conv2d_nchw_stem_fused); `d` still describes the padded NHWC4 view
 static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
-                       const float* shift, const void* residual, void* y, void* stream, bool pool, const float* gate = nullptr) {
+                       const float* shift, const void* residual, void* y, void* stream, bool pool, const float* gate = nullptr,
+                       bool x_nchw = false) {
     if (!ctx) return PCV_ERR_INVALID;
     DeviceGuard device_guard(ctx->device);
     if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
@@ -896,10 +904,13 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     if (P.stem && sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
     if (gate && (P.stem || pool)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: the stem kernel has no gate");
     if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
+    if (x_nchw && (!P.stem || d->Cin > 3 || d->W % 4 != 0))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_nchw_stem_fused: only the stem convolution (<= 3 input planes, W a multiple of 4)");
     if (P.stem) {
         StemParams q;
         q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes;
+        q.x_bytes = x_nchw ? (uint32_t)((unsigned long long)d->N * d->Cin * d->H * d->W * 4ull) : (uint32_t)xbytes;
+        q.w_bytes = (uint32_t)P.w_bytes; q.Cin = d->Cin;
         q.Hq = pool ? pool_out(P.Ho, 3, 2, 1, 0) : P.Ho;
         q.Wq = pool ? pool_out(P.Wo, 3, 2, 1, 0) : P.Wo;
         const unsigned long long ybytes = (unsigned long long)d->N * q.Hq * q.Wq * (unsigned long long)d->Cout * P.ES;
@@ -919,11 +930,19 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         long long nb = block_slots(ctx, g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1]);
         if (nb > nT) nb = nT;
         nb = (nb + 7) / 8 * 8;
-        if (pool) {
-            if (d->dtype == PCV_BF16) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
-            else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
-        } else if (d->dtype == PCV_BF16) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false>), dim3((unsigned)nb), dim3(256), kStemLds, (hipStream_t)stream, q);
+        const bool bf = d->dtype == PCV_BF16;
+        const dim3 g((unsigned)nb), b(256);
+        hipStream_t st = (hipStream_t)stream;
+        if (x_nchw) {
+            const int lds = kStemLds + kStemStageBytes;
+            if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true, true>), g, b, lds, st, q);
+            else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true, true>), g, b, lds, st, q);
+            else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false, true>), g, b, lds, st, q);
+            else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false, true>), g, b, lds, st, q);
+        } else if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true>), g, b, kStemLds, st, q);
+        else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true>), g, b, kStemLds, st, q);
+        else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false>), g, b, kStemLds, st, q);
+        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false>), g, b, kStemLds, st, q);
         HIP_TRY(ctx, hipGetLastError());
         return PCV_OK;
     }
@@ -1195,6 +1214,22 @@ int pcv_conv2d_maxpool_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x
     if (!pcv_conv2d_maxpool_supported(d, k, s, p, ceil_mode))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution followed by MaxPool2d(3, 2, 1) is covered");
     return conv2d_impl(ctx, d, x, packed, scale, shift, nullptr, y, stream, true);
+}
+
+int pcv_conv2d_nchw_stem_supported(const pcv_conv_desc* d, int pool) {
+    if (!d) return 0;
+    ConvPlan P;
+    if (plan_conv(*d, P, false) != nullptr || !P.stem || d->Cin > 3 || d->W % 4 != 0) return 0;
+    if (d->has_residual || d->post_act != PCV_ACT_NONE || (d->y_cpitch > 0 && d->y_cpitch != d->Cout)) return 0;
+    return (!pool || pcv_conv2d_maxpool_supported(d, 3, 2, 1, 0)) ? 1 : 0;
+}
+
+int pcv_conv2d_nchw_stem_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const float* x_nchw, const void* packed, const float* scale,
+                               const float* shift, void* y, int pool, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    if (!pcv_conv2d_nchw_stem_supported(d, pool))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_nchw_stem_fused: only the stride-2 stem convolution (<= 3 planes, W % 4 == 0, <= 64 channels) is covered");
+    return conv2d_impl(ctx, d, x_nchw, packed, scale, shift, nullptr, y, stream, pool != 0, nullptr, true);
 }
 
 int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,

@@ -16,6 +16,13 @@
 // activation the 3-wide column max runs across lanes with DPP row shifts (a 16-lane DPP row = the 16 conv columns of one
 // fragment), the 3-high row max in registers (a wave holds 4 consecutive conv rows) plus one row handed down from the next
 // wave through LDS. max() commutes with the monotonic rounding, so the result equals pooling the rounded tensor bit for bit.
+//
+// NCHW variant (round 2): the kernel reads the caller's fp32 NCHW image itself (the reference's input layout, resnet.py:333) - the
+// `pcv_nchw_to_nhwc` launch in front of every net (154 MB read + 103 MB written + 103 MB read again at batch 256) disappears. The
+// three fp32 planes of the patch are staged by LDS-DMA (rows of 11 16-byte chunks starting at the 4-pixel boundary at or below
+// the patch origin), then 256 threads convert them once per tile into the SAME bf16 / fp16 NHWC4 patch the kernel has always read
+// (same rounding as the layout kernel: results are bit-identical), one more barrier per tile; the staging DMA of the next tile
+// flies during this tile's MFMAs as before.
 #pragma once
 #include "pcv_common.hpp"
 #include "igemm_conv.hpp"     // Mma<DT>
@@ -34,7 +41,10 @@ struct StemParams {
     int tilesH, tilesW, nTiles;
     int act;
     int Hq, Wq;               // POOL: pooled output size; y is [N, Hq, Wq, Cout]
+    int Cin;                  // NCHW variant: planes of x (<= 3); x is fp32 [N, Cin, H, W] with W % 4 == 0, x_bytes its size
 };
+
+static constexpr int kStemStageBytes = 5 * 256 * 16;          // NCHW variant: 3 planes x 37 rows x 11 chunks = 1221 chunks of 16 B
 
 __device__ __forceinline__ float stem_row_shl(float v, int n) {      // value of lane fr + n of the same 16-lane row (0 past the end)
     const int i = __builtin_bit_cast(int, v);
@@ -43,7 +53,7 @@ __device__ __forceinline__ float stem_row_shl(float v, int n) {      // value of
 }
 
 // 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 64 (padded) channels.
-template <int DT, bool POOL = false>
+template <int DT, bool POOL = false, bool NCHW = false>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 16, TW = 16;
@@ -53,7 +63,9 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
     constexpr int WBYTES = 7 * 64 * 64;          // weights: up to 7 filter rows x 64 rows x 64 B
     constexpr int PBYTES = PCHUNKS * 16;
     typedef typename Mma<DT>::frag frag;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights | patch 0 | patch 1 | POOL: row hand-down 6 KB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [weights | patch 0 | patch 1 | POOL: row hand-down 6 KB | NCHW: staging]
+    constexpr int SFC = 11;                      // NCHW: 16-byte chunks (4 fp32 pixels) per staged plane row: 40 patch pixels + <= 2 of alignment
+    char* const stage = smem + WBYTES + 2 * PBYTES + 3 * 2 * 64 * 16;
     constexpr int TSTEP = POOL ? 14 : 16;        // conv rows / columns between tile origins
     constexpr int TORG = POOL ? -1 : 0;          // first conv row / column of tile 0
 
@@ -102,6 +114,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         const int n = t2 / p.tilesH;
         const int hi0 = (th * TSTEP + TORG) * 2 - p.pt;
         const int wp0 = (tw * TSTEP + TORG) * 2 + p.x0off;       // even
+        if constexpr (NCHW) {
+            // chunk c = 256 j + tid -> (plane, patch row, column chunk); source column = 4-aligned origin at or below wp0
+            const int wa = wp0 & ~3;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int c = 256 * j + tid;
+                const int pl = c / (SFC * 37), rem = c - pl * (SFC * 37);
+                const int r = rem / SFC, cc = rem - r * SFC;
+                const int hi = hi0 + r, wc0 = wa + 4 * cc;
+                const bool ok = pl < p.Cin && r < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wc0 < (unsigned)p.W;
+                const uint32_t off = ok ? (uint32_t)((((n * p.Cin + pl) * p.H + hi) * p.W + wc0) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(stage + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
+            }
+            return;
+        }
         char* dst0 = smem + WBYTES + buf * PBYTES;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -110,6 +137,34 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             const bool ok = prow[j] < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wp < (unsigned)p.Wp;
             const uint32_t off = ok ? (uint32_t)((((n * p.H + hi) * p.Wp + wp)) * 8) : 0x80000000u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(dst0 + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
+        }
+    };
+    // NCHW: staged fp32 planes of tile t -> the 16-bit NHWC4 patch (buffer 0): item c = 256 j + tid = (patch row, pixel pair)
+    auto convert_patch = [&](int t) {
+        const int tw = t % p.tilesW;
+        const int wp0 = (tw * TSTEP + TORG) * 2 + p.x0off;
+        const int a = wp0 & 3;                                   // 0 or 2: patch pixel 0 sits `a` floats into the staged row
+        const int Wlim = p.W - (wp0 & ~3);                       // staged columns at or beyond this are outside the image
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = a + 2 * pcol[j];                     // first of the two pixels, in staged-row floats (even)
+            float v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const f32x2 f = *reinterpret_cast<const f32x2*>(stage + ((pl * 37 + prow[j]) * SFC * 4 + col) * 4);
+                v[0][pl] = f[0];
+                v[1][pl] = f[1];
+            }
+            // (a chunk is wholly inside or wholly outside the image - W % 4 == 0 - and outside chunks were DMA'd as zeros; the
+            // limit only matters for the alignment columns of a chunk that straddles nothing: kept for clarity of intent)
+            const bool in0 = col < Wlim, in1 = col + 1 < Wlim;
+            u32x4 o;
+            o[0] = in0 ? pack2<DT>(v[0][0], v[0][1]) : 0u;
+            o[1] = in0 ? pack2<DT>(v[0][2], v[0][3]) : 0u;
+            o[2] = in1 ? pack2<DT>(v[1][0], v[1][1]) : 0u;
+            o[3] = in1 ? pack2<DT>(v[1][2], v[1][3]) : 0u;
+            if (256 * j + tid < PCHUNKS && prow[j] < 37)
+                *reinterpret_cast<u32x4*>(smem + WBYTES + (256 * j + tid) * 16) = o;
         }
     };
 
@@ -141,6 +196,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         // patch whose last pieces were still in flight (seen once in ~6 full-batch forwards as a few wrong output rows).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // weights + this tile's patch landed; other buffer free
+        if constexpr (NCHW) {
+            convert_patch(tile);                                 // staging -> patch 0 (everybody is past the previous tile's reads)
+            __syncthreads();                                     // patch complete; staging free for the next tile's planes
+        }
         if (has_next) issue_patch(ntile, buf ^ 1);
 
         f32x4 acc[4][4];
@@ -148,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const char* pbase = smem + WBYTES + buf * PBYTES + xfrag;
+        const char* pbase = smem + WBYTES + (NCHW ? 0 : buf) * PBYTES + xfrag;
         for (int r = 0; r < p.kh; ++r) {
             frag a[4], b[4];
 #pragma unroll

@@ -101,6 +101,46 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class LazyNCHW(NHWC):
+    """The network input as the caller gave it - fp32 NCHW - seen through the handle interface of its padded NHWC4 view. The stem
+    kernel reads the fp32 planes itself (`ConvRunner._stem_from_nchw`, pcv_conv2d_nchw_stem_fused); anything else that asks for
+    `.t` gets the converted tensor (pcv_nchw_to_nhwc, once)."""
+    __slots__ = ("src", "_conv", "_dtype_name")
+
+    def __init__(self, x: torch.Tensor, dtype: str):
+        N, C, H, W = x.shape
+        self.src, self._conv, self._dtype_name = x, None, dtype
+        self.N, self.H, self.W, self.C = N, H, W, C
+        self.wpitch, self.cpitch = (W + 1) // 2 * 2, 4
+
+    @property
+    def t(self):
+        if self._conv is None:
+            self._conv = from_nchw(self.src, self._dtype_name, stem=True).t
+        return self._conv
+
+    @property
+    def materialized(self) -> bool:
+        return self._conv is not None
+
+    @property
+    def dtype(self):
+        return DTYPES[self._dtype_name][1]
+
+    @property
+    def device(self):
+        return self.src.device
+
+
+def network_input(x: torch.Tensor, dtype: str) -> NHWC:
+    """Handle of a net's fp32 NCHW input: lazy (the stem kernel reads the planes directly) when the stem layout applies."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW tensor")
+    if x.shape[1] <= 3 and x.shape[3] % 4 == 0 and STEM_FROM_NCHW:
+        return LazyNCHW(x.contiguous().float(), dtype)
+    return from_nchw(x, dtype, stem=True)
+
+
 def from_nchw(x: torch.Tensor, dtype: str, stem: bool = True) -> NHWC:
     """fp32 NCHW -> NHWC handle (pcv_nchw_to_nhwc). With `stem`, C <= 4 is padded to 4 channels and W to even."""
     if x.dim() != 4:
@@ -278,9 +318,35 @@ class ConvRunner(object):
         a padding-0 convolution, efficientnet.py:108-109,189-190,236-237); it stays inside the kernel's bounds checks."""
         if self.bn is not None and self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        if isinstance(x, LazyNCHW) and not x.materialized and residual is None and out is None and gate is None and not out_fp32 \
+                and post_act == 0 and pad4 is None:
+            y = self._stem_from_nchw(x, act, pool=False)
+            if y is not None:
+                return y
         d = self.desc(x, act, post_act, residual is not None, out_code=0 if out_fp32 else None, logits=out_fp32, pad4=pad4)
         self.prepare(x, d)
         return self._launch(x, d, residual, out, gate)
+
+    def _stem_from_nchw(self, x: "LazyNCHW", act: int, pool: bool):
+        """The stem convolution (+ the init block's MaxPool2d(3, 2, 1) with `pool`) straight from the fp32 NCHW image
+        (pcv_conv2d_nchw_stem_fused); None when this convolution is not the covered stem shape."""
+        if self.depthwise or self.pad4 is not None:
+            return None
+        d = self.desc(x, act, 0, False)
+        L, ctx = _lib.lib(), _ctx(x.device)
+        if not L.pcv_conv2d_nchw_stem_supported(ctypes.byref(d), 1 if pool else 0):
+            return None
+        self.prepare(x, d)
+        Ho = (x.H + d.pad_t + d.pad_b - d.dil_h * (d.kh - 1) - 1) // d.stride_h + 1
+        Wo = (x.W + d.pad_l + d.pad_r - d.dil_w * (d.kw - 1) - 1) // d.stride_w + 1
+        if pool:
+            Ho, Wo = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        if Ho <= 0 or Wo <= 0:
+            return None
+        y = torch.empty((x.N, Ho, Wo, d.Cout), dtype=x.dtype, device=x.device)
+        _lib.check(L.pcv_conv2d_nchw_stem_fused(ctx, ctypes.byref(d), _ptr(x.src), _ptr(self.packed), _ptr(self.scale), _ptr(self.shift),
+                                                _ptr(y), 1 if pool else 0, _stream(x.device)), ctx)
+        return NHWC(y, x.N, Ho, Wo, self.conv.out_channels, cpitch=d.Cout)
 
     def run_maxpool(self, x: NHWC, act: int, k: int, s: int, p: int, ceil_mode: bool = False):
         """This convolution + BN + activation and the MaxPool2d(k, s, p) behind it as ONE launch when covered
@@ -289,6 +355,10 @@ class ConvRunner(object):
             return None
         if self.bn is not None and self.bn.training:
             raise RuntimeError("pytorchcv_amd is an inference path: call net.eval() first (BatchNorm is folded)")
+        if isinstance(x, LazyNCHW) and not x.materialized and (k, s, p) == (3, 2, 1) and not ceil_mode:
+            y = self._stem_from_nchw(x, act, pool=True)
+            if y is not None:
+                return y
         d = self.desc(x, act, 0, False)
         L, ctx = _lib.lib(), _ctx(x.device)
         if not L.pcv_conv2d_maxpool_supported(ctypes.byref(d), k, s, p, 1 if ceil_mode else 0):
@@ -545,6 +615,7 @@ def avgpool2d(x: NHWC, k: int, s: int, out_fp32: bool = False) -> NHWC:
 # map, the rounding of the pooled vector and of the classifier weights is not - those two roundings alone were 43 % of the
 # noise power of ResNet-50's bf16 logits (max |d| vs the fp32 reference 1.1e-2 -> 8.1e-3, ResNeXt-101 1.3e-2 -> 8.9e-3).
 FP32_HEAD = os.environ.get("PCV_AMD_FP32_HEAD", "1") != "0"
+STEM_FROM_NCHW = os.environ.get("PCV_AMD_STEM_NCHW", "1") != "0"     # the stem reads the fp32 NCHW input itself (0: layout kernel first)
 
 
 # Unit-level fusions (pcv_mbconv_fused, pcv_conv1x1_pair_fused) can be switched off to time the per-layer kernels on their own

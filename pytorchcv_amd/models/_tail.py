@@ -99,7 +99,7 @@ def run_net(net: nn.Module, x, head, stem: bool = True):
         return head(net.features(x))
     if not torch.is_tensor(x) or x.dim() != 4:
         raise TypeError("expected an NCHW tensor")
-    a = engine.from_nchw(x, engine.compute_dtype_of(net), stem=stem)
+    a = engine.network_input(x, engine.compute_dtype_of(net)) if stem else engine.from_nchw(x, engine.compute_dtype_of(net), stem=False)
     return head(net.features(a))
 
 

@@ -588,3 +588,31 @@ def test_conv1x1_eight_wave_mode_equals_generic(shape, dtype, grid, cuda_device)
     assert bool(torch.isfinite(outs["generic"].float()).all())
     for name in ("auto", "128x224", "256x112"):
         assert torch.equal(outs[name], outs["generic"]), "{}: {} elements differ".format(name, int((outs[name] != outs["generic"]).sum()))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("kind", ["mobilenet3x3", "resnet7x7pool", "resnet7x7"])
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 32, 32), (2, 61, 224), (1, 30, 28), (5, 70, 52), (2, 33, 35)])
+def test_stem_from_nchw_equals_layout_kernel_plus_stem(shape, kind, dtype, grid, cuda_device):
+    """The stem kernel reading the fp32 NCHW image itself (pcv_conv2d_nchw_stem_fused) against pcv_nchw_to_nhwc + the same
+    kernel on the NHWC4 tensor: bit-identical (the in-kernel conversion rounds like the layout kernel). W % 4 != 0 keeps the
+    two-launch path (network_input returns the converted handle)."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block, conv7x7_block
+    from pytorchcv_amd.models.resnet import ResInitBlock
+    N, H, W = shape
+    blk = {"mobilenet3x3": lambda: conv3x3_block(in_channels=3, out_channels=32, stride=2),
+           "resnet7x7pool": lambda: ResInitBlock(3, 64), "resnet7x7": lambda: conv7x7_block(in_channels=3, out_channels=64, stride=2)}[kind]().eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=4))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, 3, H, W, seed=14).to(cuda_device)
+    with torch.no_grad(), util.tuning(max_blocks=grid):
+        a = engine.network_input(x, dtype)
+        assert isinstance(a, engine.LazyNCHW) == (W % 4 == 0)
+        y_direct = blk(a)
+        assert not isinstance(a, engine.LazyNCHW) or not a.materialized, "the fp32 image must not have been converted"
+        y_two = blk(engine.from_nchw(x, dtype, stem=True))
+    torch.cuda.synchronize()
+    assert y_direct.t.shape == y_two.t.shape and torch.equal(y_direct.t, y_two.t)
