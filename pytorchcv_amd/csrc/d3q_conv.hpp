@@ -62,6 +62,8 @@ struct D3Params {
     int act, post_act;
     int nChTiles, nTiles;
     uint32_t* dbg;          // diagnostic builds only (-DD3X3_STAMPS)
+    int stride, Hin, Win;   // 1x1 mode only: output pixel (n, ho, wo) reads input pixel (n, stride ho, stride wo) of an Hin x Win map
+                            // (H, W, HW, div_hw, div_w then describe the OUTPUT map)
 };
 
 // In-kernel stamps (cdna_hip_programming.md section 7): a diagnostic build (-DD3X3_STAMPS) times ONE section per K-step - the
@@ -209,8 +211,15 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
             if (u < BP + 2 && m >= 0 && m < p.M) {
                 const uint32_t n = fastdiv((uint32_t)m, p.div_hw);
                 const uint32_t ho = fastdiv((uint32_t)m - n * (uint32_t)p.HW, p.div_w);
-                off = (uint32_t)((m * p.Cin + cs * 8) * 2);
-                vm = ONE ? 7u : ((ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u));
+                if constexpr (ONE) {
+                    const uint32_t wo = (uint32_t)m - n * (uint32_t)p.HW - ho * (uint32_t)p.W;
+                    const uint32_t mi = (n * (uint32_t)p.Hin + ho * (uint32_t)p.stride) * (uint32_t)p.Win + wo * (uint32_t)p.stride;
+                    off = (uint32_t)((mi * (uint32_t)p.Cin + (uint32_t)cs * 8u) * 2u);
+                    vm = 7u;
+                } else {
+                    off = (uint32_t)((m * p.Cin + cs * 8) * 2);
+                    vm = (ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u);
+                }
             }
             pbv[j] = off;
             vmask[j / 10] |= vm << (3 * (j % 10));

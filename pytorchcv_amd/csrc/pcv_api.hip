@@ -999,6 +999,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.HW = d->H * d->W;
         q.div_hw = make_fastdiv((uint32_t)q.HW);
         q.div_w = make_fastdiv((uint32_t)d->W);
+        q.stride = 1; q.Hin = d->H; q.Win = d->W;
         q.nk = P.nk; q.slices = d->Cin / 64; q.Kpad = P.Kpad;
         q.act = d->act; q.post_act = d->post_act;
         q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
@@ -1016,7 +1017,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     // ---- K-heavy 1x1 / stride 1, 16 bit: d3q_kernel's 1x1 mode ---------------------------------------------------------------------
     int d1shape = -1;
     if (ctx->use_d1x1 != 0 && !gate && !P.pair && d->dtype != PCV_F32 && d->out_dtype == d->dtype && d->kh == 1 && d->kw == 1 &&
-        d->stride_h == 1 && d->stride_w == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
+        d->stride_h == d->stride_w && d->stride_h <= 2 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
         cpitch == d->Cin && wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && d->act <= PCV_ACT_RELU6 &&
         d->post_act <= PCV_ACT_RELU6 && scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
         d1shape = ctx->use_d1x1 > 0 ? std::min(ctx->use_d1x1 - 1, kD1Count - 1)
@@ -1037,9 +1038,10 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes1;
         q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
         q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch1;
-        q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.HW = d->H * d->W;
+        q.H = P.Ho; q.W = P.Wo; q.Cin = d->Cin; q.HW = P.Ho * P.Wo;                 // the OUTPUT map (a strided 1x1 reads every stride-th pixel)
         q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.div_w = make_fastdiv((uint32_t)P.Wo);
+        q.stride = d->stride_h; q.Hin = d->H; q.Win = d->W;
         q.nk = d->Cin / 64; q.slices = q.nk; q.Kpad = P.Kpad;
         q.act = d->act; q.post_act = d->post_act;
         q.nChTiles = (d->Cout + S.BM - 1) / S.BM;

@@ -556,9 +556,10 @@ def test_stem_full_batch_is_repeatable(kind, cuda_device):
             assert torch.equal(y, want), "pass {}: {} images differ".format(rep, int((y != want).flatten(1).any(1).sum()))
 
 
-_D1_SHAPES = [  # (N, Cin, Cout, H, W, residual): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
+_D1_SHAPES = [  # (N, Cin, Cout, H, W, residual[, stride]): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
     (16, 1024, 512, 14, 14, False), (16, 512, 1024, 14, 14, True), (9, 2048, 512, 7, 7, False), (5, 512, 2048, 7, 7, True),
     (3, 576, 136, 13, 11, False), (2, 64, 256, 20, 20, True), (1, 192, 72, 5, 9, False),
+    (6, 256, 512, 56, 56, False, 2), (5, 512, 256, 28, 28, False, 2), (3, 1024, 2048, 14, 14, False, 2), (2, 256, 128, 13, 11, False, 2),
 ]
 
 
@@ -571,12 +572,13 @@ def test_conv1x1_eight_wave_mode_equals_generic(shape, dtype, grid, cuda_device)
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv1x1_block
-    N, C, Cout, H, W, use_res = shape
-    blk = conv1x1_block(in_channels=C, out_channels=Cout).eval()
+    N, C, Cout, H, W, use_res = shape[:6]
+    stride = shape[6] if len(shape) > 6 else 1
+    blk = conv1x1_block(in_channels=C, out_channels=Cout, stride=stride).eval()
     blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=83))
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
     x = util.synth_input(N, C, H, W, seed=29)
-    res = util.synth_input(N, Cout, H, W, seed=30) if use_res else None
+    res = util.synth_input(N, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, seed=30) if use_res else None
     outs = {}
     with torch.no_grad():
         xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
