@@ -2,7 +2,9 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name']]
+# a forward starts at the stem kernel (which reads the fp32 NCHW input itself since round 2) or at the layout kernel in front of it
+idx = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r['Kernel_Name'] or 'stem_conv_kernel' in r['Kernel_Name']]
+idx = [i for k, i in enumerate(idx) if k == 0 or i != idx[k - 1] + 1]          # (layout kernel + stem = one start)
 a, b = idx[-2], idx[-1]
 tot = 0
 for r in rows[a:b]:
