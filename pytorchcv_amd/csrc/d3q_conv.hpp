@@ -113,8 +113,11 @@ template <int WC, int WP, int CBW, int PBW, int KS, bool ONE = false> struct D3C
     static constexpr int BSZ = NPB * 1024;                   // bytes of one B slot
     static constexpr int NSA = 3;
     static constexpr int NSB = ONE ? 3 : 2;
-    static constexpr int ZOFF = NSA * ASZ + NSB * BSZ;       // 128 zero bytes: the row a horizontally padded tap reads
-    static constexpr int DUMP = ZOFF + 128;                  // 1 KB: where the (NLOAD XLW - NPB) surplus pieces of a group land (every
+    // 2 KB of zeros (16 rows), 2 KB-aligned: a horizontally padded tap reads the zero block at the SAME offset inside its 2 KB
+    // window as the row it replaces, i.e. through the same LDS banks - one shared 16-byte zero chunk put 1.9 conflict cycles on
+    // every fragment read of the 3x3 mode (SQ_LDS_BANK_CONFLICT: 4.5 M per launch; the 1x1 mode, which never masks, had none)
+    static constexpr int ZOFF = (NSA * ASZ + NSB * BSZ + 2047) / 2048 * 2048;
+    static constexpr int DUMP = ZOFF + 2048;                 // 1 KB: where the (NLOAD XLW - NPB) surplus pieces of a group land (every
                                                              // loader issues the same number of pieces: the vmcnt counts are constants)
     static constexpr int LDS = DUMP + 1024;
     static_assert(WC * WP == 8, "eight compute waves");
@@ -258,7 +261,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     // prologue: weight tiles of K-steps 0 and 1, activation tile of group 0, the zero row
     setup_a(T.tile0);
     setup_b(T.tile0);
-    if (lw == 0 && lane < 8) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + lane * 16)) = (u32x4){0u, 0u, 0u, 0u};
+    if (lw < 2) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + (lw * 64 + lane) * 16)) = (u32x4){0u, 0u, 0u, 0u};
     dma_b(C0{}, CBN{});
     advance_b();
     dma_a(C0{}, CAN{});
@@ -388,6 +391,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
             const uint32_t kc = (uint32_t)(fq + 4 * (h * KS + u));
             lds_cptr ap = (lds_cptr)(size_t)(abase + ((kc ^ (uint32_t)(fr & 7)) << 4));
             lds_cptr bp = (lds_cptr)(size_t)(bbase + ((kc ^ (brow & 7u)) << 4));
+            const uint32_t zsel = zrow + ((uint32_t)(size_t)bp & 2047u);        // the zero block through this lane's own banks
 #pragma unroll
             for (int i = 0; i < CBW; ++i) a[u][i] = *reinterpret_cast<lds_fptr>(ap + i * 2048);
 #pragma unroll
@@ -395,7 +399,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 lds_cptr bj = bp;
                 if constexpr (Q != 1) {
                     const uint32_t t = (uint32_t)__builtin_amdgcn_sbfe((int)(Q == 0 ? hm0 : hm2), j, 1);   // all ones: horizontally padded tap
-                    bj = (lds_cptr)(size_t)((t & (zrow - (uint32_t)(j * 2048))) | (~t & (uint32_t)(size_t)bp));
+                    bj = (lds_cptr)(size_t)((t & (zsel - (uint32_t)(j * 2048))) | (~t & (uint32_t)(size_t)bp));
                 }
                 b[u][j] = *reinterpret_cast<lds_fptr>(bj + j * 2048);
             }
