@@ -36,7 +36,8 @@ struct MbwLds {
 // 16-pixel blocks over the input window of a wave tile
 static inline __host__ __device__ int mbw_npt(int stride, int tw) {
     const int nblk = stride == 1 ? 4 : 2, ro = nblk * (16 / tw);
-    return (((ro - 1) * stride + 3) * ((tw - 1) * stride + 3) + 15) / 16;          // 7 / 7 (stride 1), 11 / 10 (stride 2)
+    const int iw = (tw - 1) * stride + 3, iws = iw + ((stride == 2 && tw == 8) ? 1 : 0);      // storage pitch of a window row
+    return (((ro - 1) * stride + 3) * iws + 15) / 16;                                        // 7 / 7 (stride 1), 11 / 11 (stride 2)
 }
 // ka: K steps of the expand GEMM (Cin <= 32 ka). With ka == 1 the two 1x1 weight matrices live in LDS; wider units (64 -> 384 ->
 // 64 is 98 KB of weights) leave them in L2 and every wave fetches its fragments per chunk.
@@ -82,7 +83,11 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     constexpr int PR = 16 / TW;                         // output rows of a pixel block
     constexpr int RO = R * PR;                          // output rows of the tile
     constexpr int IH = (RO - 1) * S + 3, IW = (TW - 1) * S + 3;
-    constexpr int NIP = IH * IW;                        // window pixels: 108 / 100 (stride 1), 165 / 153 (stride 2)
+    // Storage pitch of a window row. A 2 x 8 pixel block reads two runs of 8 rows: conflict-free when the runs are 8 k rows apart,
+    // so its two output rows are R apart (stride 1: 4 x 10 = 40 storage rows) and the stride-2 window row is padded 17 -> 18
+    // (4 x 18 = 72); the 1 x 16 blocks read 16 consecutive rows and need neither.
+    constexpr int IWS = IW + ((S == 2 && TW == 8) ? 1 : 0);
+    constexpr int NIP = IH * IWS;                       // stored window pixels: 108 / 100 (stride 1), 165 / 162 (stride 2)
     constexpr int NPT = (NIP + 15) / 16;
     // The two-K-step variant has no registers for a table of swizzled S2 addresses (and computing them per read cost 24 %): it keeps
     // round 2's first layout - unswizzled rows on an 80-byte pitch, every S2 address an immediate off 5 registers, 2.7 conflict cycles
@@ -147,9 +152,9 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #pragma unroll
     for (int m = 0; m < NPT; ++m) {
         const int ip = 16 * m + fr;                                                // storage index of the window pixel this lane expands
-        const int wr = ip / IW, cc = ip % IW;
+        const int wr = ip / IWS, cc = ip % IWS;
         const int wcol = S == 1 ? cc : (cc < IWH ? 2 * cc : 2 * (cc - IWH) + 1);
-        prc[m] = ip < NIP ? (uint32_t)((wr << 8) | wcol) : 0xFF00u;
+        prc[m] = (ip < NIP && wcol < IW) ? (uint32_t)((wr << 8) | wcol) : 0xFF00u;
     }
     // S2: A (weights, rows = channels) lane (row fr, k quarter fq) holds tap (fq >> 1) of the pair, channels 8 (fq & 1) .. + 7 of the
     // 16-channel half: non-zero only on the diagonal, element fr & 7 when (fr >> 3) == (fq & 1). B (E tile, columns = the 16 pixels
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const int tap = min(2 * j + (fq >> 1), 8);                             // tap 9 has zero weights: any valid address
-            const int wr = (u * PR + pr) * S + tap / 3, wcol = pc * S + tap % 3;
-            const int sidx = wr * IW + (S == 1 ? wcol : (wcol & 1) * IWH + (wcol >> 1));
+            const int wr = (u + R * pr) * S + tap / 3, wcol = pc * S + tap % 3;       // pixel block u = output rows u (and u + R)
+            const int sidx = wr * IWS + (S == 1 ? wcol : (wcol & 1) * IWH + (wcol >> 1));
             boff[u][j] = (uint32_t)(sidx * PITCH + (((fq & 1) ^ mbw_swz<SWZ>(sidx)) << 4));
         }
     const int fsw = (fq ^ mbw_swz<SWZ>(fr)) << 4;                                       // fragment access of row (16 k + fr), slot fq
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                         if constexpr (BTAB) {
                             ba = boff[u][j];
                         } else {
-                            ba = boff[0][j] + (uint32_t)(u * PR * S * IW * PITCH);
+                            ba = boff[0][j] + (uint32_t)(u * S * IWS * PITCH);
                         }
                         const frag b = *reinterpret_cast<const frag*>(Es + (g == 0 ? ba : (SWZ ? (ba ^ 32u) : ba + 32u)));
                         da = Mma<DT>::run(af[j], b, da);
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
             }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
-                const int ho = ho0 + u * PR + pr, wo = wo0 + pc;
+                const int ho = ho0 + u + R * pr, wo = wo0 + pc;
                 const bool ok = ch < p.Cout && ho < p.Ho && wo < p.Wo;
                 const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wo) * p.Cout + ch) * 2) : 0x80000000u;
                 float v[8];
