@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 16, TW = 16;
     constexpr int PCH = 20;                      // 16-byte chunks (pixel pairs) per patch row: 2*15 + 2*3 + 2 -> 20
-    constexpr int PRMAX = 2 * (TH - 1) + 7;      // 37 patch rows for kh = 7
     constexpr int PCHUNKS = 768;                 // 3 DMA instructions per thread (>= PRMAX * PCH = 740)
     constexpr int WBYTES = 7 * 64 * 64;          // weights: up to 7 filter rows x 64 rows x 64 B
     constexpr int PBYTES = PCHUNKS * 16;
