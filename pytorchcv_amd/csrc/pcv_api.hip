@@ -906,6 +906,8 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
     if (x_nchw && (!P.stem || d->Cin > 3 || d->W % 4 != 0))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_nchw_stem_fused: only the stem convolution (<= 3 input planes, W a multiple of 4)");
+    if (x_nchw && (unsigned long long)d->N * d->Cin * d->H * d->W * 4ull >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_nchw_stem_fused: the fp32 image batch exceeds the 2 GiB window of one launch; split the batch");
     if (P.stem) {
         StemParams q;
         q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;

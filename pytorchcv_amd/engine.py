@@ -330,8 +330,8 @@ class ConvRunner(object):
     def _stem_from_nchw(self, x: "LazyNCHW", act: int, pool: bool):
         """The stem convolution (+ the init block's MaxPool2d(3, 2, 1) with `pool`) straight from the fp32 NCHW image
         (pcv_conv2d_nchw_stem_fused); None when this convolution is not the covered stem shape."""
-        if self.depthwise or self.pad4 is not None:
-            return None
+        if self.depthwise or self.pad4 is not None or x.src.numel() * 4 >= (1 << 31):      # (one launch addresses < 2 GiB: the
+            return None                                                                      # converted path splits the batch)
         d = self.desc(x, act, 0, False)
         L, ctx = _lib.lib(), _ctx(x.device)
         if not L.pcv_conv2d_nchw_stem_supported(ctypes.byref(d), 1 if pool else 0):
