@@ -5,7 +5,7 @@
 // segment is gathered nine times from L2 and 50-88 % of the MFMA work multiplies zeros; the layers reach 1.5 TB/s (0.2 of the
 // HBM peak) although they are pure streaming (3x3 x 4..16 MACs per output). Here:
 //   * a block owns 64 channels (whole groups) x 128 pixels; the activation tile with its halo (flat pixel range
-//     [p0 - WPAD, p0 + 128 + WPAD) of 128-byte rows, hconv3x3.hpp's scheme: taps are row shifts (r-1) W + (q-1), borders are
+//     [p0 - WPAD, p0 + 128 + WPAD) of 128-byte rows: taps are row shifts (r-1) W + (q-1), borders are
 //     resolved by zeroing the B fragment of a lane whose pixel leaves the image) is staged ONCE by LDS-DMA, double buffered;
 //   * the K axis of one MFMA is (2 taps) x (16 input channels): a 16-channel slab (= 4, 2 or 1 whole groups) needs 5 K-steps for
 //     its 9 taps (the 10th is zero weight) instead of 18 K-steps x 4 row fragments per 64 channels; inside a slab the weight
