@@ -425,6 +425,22 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
     // Packed weight row (16 i + rho) of a 64-row group holds channel 32 (i >> 1) + 8 (rho >> 2) + 4 (i & 1) + (rho & 3): lane group
     // fq owns the 8 consecutive channels 32 ip + 8 fq .. + 7 of a pixel (accumulators 2 ip and 2 ip + 1).
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+    // The BN scale / shift of the wave's channels are requested at the START of the tile's last K-step, and a convolution WITHOUT skip
+    // connection no longer issues residual loads at all (zero-record buffer loads return zeros but still take the memory pipeline's
+    // ~1 us; fetched inside the epilogue these latencies stood between two tiles' K loops: 2 590 cycles per K-step on the 9-K-step
+    // tiles of the 64-channel layers against ~1 500 elsewhere). The residual tile itself stays in the epilogue (28 registers).
+    const bool has_res = p.res != nullptr;
+    f32x4 es0[CBW / 2], es1[CBW / 2], eh0[CBW / 2], eh1[CBW / 2];
+    auto ep_prefetch = [&](int t) __attribute__((always_inline)) {
+        const int chTile = t % p.nChTiles;
+#pragma unroll
+        for (int ip = 0; ip < CBW / 2; ++ip) {
+            const int ch0 = chTile * BM + wc * 16 * CBW + 32 * ip + 8 * fq;
+            const int chl = ch0 < p.Cout ? ch0 : 0;              // table index of a pad channel: any valid one (never stored)
+            es0[ip] = *reinterpret_cast<const f32x4*>(p.scale + chl); es1[ip] = *reinterpret_cast<const f32x4*>(p.scale + chl + 4);
+            eh0[ip] = *reinterpret_cast<const f32x4*>(p.shift + chl); eh1[ip] = *reinterpret_cast<const f32x4*>(p.shift + chl + 4);
+        }
+    };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int chTile = t % p.nChTiles;
         const int tileP0 = (t / p.nChTiles) * BP;
@@ -433,15 +449,17 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         for (int ip = 0; ip < CBW / 2; ++ip) {
             const int ch0 = chTile * BM + wc * 16 * CBW + 32 * ip + 8 * fq;
             const bool chok = ch0 < p.Cout;
-            const int chl = chok ? ch0 : 0;                      // table index of a pad channel: any valid one (never stored)
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(p.scale + chl), s1 = *reinterpret_cast<const f32x4*>(p.scale + chl + 4);
-            const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.shift + chl), h1 = *reinterpret_cast<const f32x4*>(p.shift + chl + 4);
+            const f32x4 s0 = es0[ip], s1 = es1[ip], h0 = eh0[ip], h1 = eh1[ip];
             u32x4 rr[PBW];
 #pragma unroll
-            for (int j = 0; j < PBW; ++j) {
-                const int m = mBase + 16 * j;
-                const uint32_t roff = (chok && m < p.M) ? (uint32_t)(((size_t)m * p.Cout + ch0) * 2) : 0x80000000u;
-                rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);        // no residual: zero records -> zeros
+            for (int j = 0; j < PBW; ++j) rr[j] = (u32x4){0u, 0u, 0u, 0u};
+            if (has_res) {
+#pragma unroll
+                for (int j = 0; j < PBW; ++j) {
+                    const int m = mBase + 16 * j;
+                    const uint32_t roff = (chok && m < p.M) ? (uint32_t)(((size_t)m * p.Cout + ch0) * 2) : 0x80000000u;
+                    rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
+                }
             }
 #pragma unroll
             for (int j = 0; j < PBW; ++j) {
@@ -499,6 +517,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
             }
             if (s == K_total) return true;
         }
+        if (k == nk - 1) ep_prefetch(cur_tile);
         if constexpr (GRP == 0) {
             reads(sa, sb, Qc, 0);
             reads_done();
@@ -546,6 +565,9 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         D3_STAMP(8);
         return false;
     };
+#ifdef D3Q_CYCLES                                              // diagnostic build: shader cycles / real time of this block's K loop (tests/tools/d3q_cycles.py)
+    const uint64_t cyc0__ = __builtin_amdgcn_s_memtime(), rt0__ = __builtin_amdgcn_s_memrealtime();
+#endif
     if constexpr (ONE) {
         for (int s = 0;; ++s)
             if (kstep(s, std::integral_constant<int, 1>{})) break;        // the unmasked centre column: tile row u holds pixel P0 + u - 1
@@ -558,6 +580,13 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
     }
 #ifdef D3X3_STAMPS
     if (p.dbg != nullptr && blockIdx.x == 16) p.dbg[wave * 64 + lane] = (uint32_t)stamps;
+#endif
+#ifdef D3Q_CYCLES
+    if (p.dbg != nullptr && blockIdx.x == 16 && wave == 0 && lane == 0) {
+        p.dbg[0] = (uint32_t)(__builtin_amdgcn_s_memtime() - cyc0__);
+        p.dbg[1] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0__);
+        p.dbg[2] = (uint32_t)K_total;
+    }
 #endif
 }
 #endif  // __HIP_DEVICE_COMPILE__
