@@ -160,6 +160,34 @@ def test_batch_split_beyond_2gib_window(cuda_device):
     torch.cuda.empty_cache()
 
 
+def test_nchw_stem_beyond_2gib_window_falls_back(cuda_device):
+    """An fp32 NCHW image batch of 2 GiB or more cannot be addressed by one launch of the NCHW stem: the lazy input handle converts
+    itself (pcv_nchw_to_nhwc) and the stem runs on the converted tensor, split by the host where its own tensors exceed the window.
+    Every image equals the small-batch result bit for bit."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    N, H = 45000, 64                                  # 45000*3*64*64*4 B = 2.21 GB
+    blk = conv3x3_block(in_channels=3, out_channels=32, stride=2).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=3))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), "bf16")
+    base = util.synth_input(500, 3, H, H, seed=21).to(cuda_device)
+    x = base.repeat(N // 500, 1, 1, 1).contiguous()
+    assert x.numel() * 4 >= 2 ** 31
+    with torch.no_grad():
+        a = engine.network_input(x, "bf16")
+        assert isinstance(a, engine.LazyNCHW)
+        y = blk(a).t
+        assert a.materialized, "the 2 GiB image batch must have gone through the layout kernel"
+        small = engine.network_input(base, "bf16")
+        y_small = blk(small).t
+        assert not small.materialized
+    assert y.shape[0] == N
+    assert torch.equal(y[:500], y_small) and torch.equal(y[N - 500:], y_small) and torch.equal(y[22000:22500], y_small)
+    del x, y, a
+    torch.cuda.empty_cache()
+
+
 def test_graph_replay_equals_eager(cuda_device):
     """hipGraph capture of the whole forward: bit-identical to eager, for new input contents too."""
     from pytorchcv_amd.graph import capture
