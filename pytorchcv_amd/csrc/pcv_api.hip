@@ -14,6 +14,7 @@
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
 #include "gconv3x3.hpp"
+#include "gconv3x3r.hpp"
 #include "mbconv.hpp"
 #include "mbw_inst.hpp"
 MBW_SHAPES(MBW_DECLARE, PCV_BF16)
@@ -41,6 +42,7 @@ struct pcv_ctx {
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
     int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp; 8 / 16: force that pixel-block width); 0: mbconv.hpp
+    int use_gconvr = 1;         // grouped 3x3 stride 2 / 32 channels per group on the row-tile kernel (gconv3x3r.hpp); 0 = generic implicit GEMM
     int use_d1x1 = -1;          // K-heavy 1x1 layers on d3q_kernel's 1x1 mode: -1 = pick_d1x1, 0 = never, n > 0 = force shape n - 1 where eligible
     int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
@@ -106,7 +108,8 @@ struct ConvPlan {
     int nchunks = 0, nk = 0, Kpad = 0;
     int wrows = 0;
     size_t ktab_bytes = 0, w_bytes = 0, total_bytes = 0;
-    bool gconv = false;       // grouped 3x3/s1/p1 with 4/8/16 channels per group: a second blob for gconv3x3.hpp follows the generic
+    int gconv_kt = 5;         // K-steps per slab of that blob: 5 (tap pairs x 16 channels; 4/8/16 channels per group) or 9 (taps x 32 channels)
+    bool gconv = false;       // grouped 3x3/p1, stride 1 or 2, 4/8/16/32 channels per group: a second blob for gconv3x3(r).hpp follows the generic
     size_t gconv_off = 0;     // one (the choice between the two kernels depends on the map width, known only at launch)
     std::vector<uint32_t> ktab;   // built only when tables == true
     std::vector<uint32_t> ksrc;
@@ -185,12 +188,14 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
     // grouped 3x3: a second blob in gconv3x3.hpp's layout behind the generic one (everything here is static; whether the launch
     // can take that kernel also depends on the map width)
     static const bool gconv_on = !(std::getenv("PCV_AMD_GCONV") && std::atoi(std::getenv("PCV_AMD_GCONV")) == 0);
-    P.gconv = gconv_on && d.groups > 1 && d.kh == 3 && d.kw == 3 && d.stride_h == 1 && d.stride_w == 1 && d.dil_h == 1 && d.dil_w == 1 &&
+    P.gconv = gconv_on && d.groups > 1 && d.kh == 3 && d.kw == 3 && d.stride_h == d.stride_w && (d.stride_h == 1 || d.stride_h == 2) &&
+              d.dil_h == 1 && d.dil_w == 1 &&
               d.pad_t == 1 && d.pad_l == 1 && d.pad_b == 1 && d.pad_r == 1 && d.Cin == d.Cout && d.Cin % 64 == 0 && P.ES == 2 &&
-              (P.Cg_in == 4 || P.Cg_in == 8 || P.Cg_in == 16) && d.out_dtype == d.dtype;
+              (P.Cg_in == 4 || P.Cg_in == 8 || P.Cg_in == 16 || P.Cg_in == 32) && d.out_dtype == d.dtype;
     if (P.gconv) {
+        P.gconv_kt = P.Cg_in == 32 ? 9 : 5;
         P.gconv_off = (P.total_bytes + 15) / 16 * 16;
-        P.total_bytes = P.gconv_off + (size_t)(d.Cin / 16) * 5 * 16 * 32 * P.ES;
+        P.total_bytes = P.gconv_off + (size_t)(d.Cin / 16) * P.gconv_kt * 16 * 32 * P.ES;
     }
     if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
 
@@ -340,6 +345,40 @@ static GConvLaunch pick_gconv(int dt, int W) {
     if (W + 1 <= 16) return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 16> : gconv3x3_kernel<PCV_F16, 16>, GConvCfg<16>::LDS};
     if (W + 1 <= 32) return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 32> : gconv3x3_kernel<PCV_F16, 32>, GConvCfg<32>::LDS};
     return GConvLaunch{bf ? gconv3x3_kernel<PCV_BF16, 64> : gconv3x3_kernel<PCV_F16, 64>, GConvCfg<64>::LDS};
+}
+// ---- row-tile grouped kernel (gconv3x3r.hpp): R whole output rows per tile, R Wo <= 64, window rows a multiple of 32 ----------
+typedef void (*gconvr_fn)(const GConvRParams);
+static gconvr_fn pick_gconvr(int dt, int stride, int kt) {
+    const bool bf = dt == PCV_BF16;
+    if (stride == 2) {
+        if (kt == 9) return bf ? gconv3x3r_kernel<PCV_BF16, 2, 9> : gconv3x3r_kernel<PCV_F16, 2, 9>;
+        return bf ? gconv3x3r_kernel<PCV_BF16, 2, 5> : gconv3x3r_kernel<PCV_F16, 2, 5>;
+    }
+    return bf ? gconv3x3r_kernel<PCV_BF16, 1, 9> : gconv3x3r_kernel<PCV_F16, 1, 9>;   // stride 1, <= 16 channels per group: gconv3x3.hpp
+}
+struct GConvRPlan { int R, XH, xl, win; };
+static bool plan_gconvr(int stride, int H, int W, int Ho, int Wo, GConvRPlan& g) {
+    if (stride == 2 && ((H | W) & 1)) return false;                // the flat-row identity needs H = 2 Ho, the parity split W = 2 Wo
+    if (Wo > 64 || Ho <= 0) return false;
+    for (int R = 64 / Wo; R >= 1; --R) {
+        const int win = stride == 2 ? (2 * R + 1) * W + 2 : (R + 2) * W + 2;
+        const int XH = stride == 2 ? ((win + 1) / 2 + 7) / 8 * 8 : 0;
+        const int rows = ((stride == 2 ? 2 * XH : win) + 31) / 32 * 32;
+        const int lds = 2 * rows * 128;
+        if (lds * 2 <= 160 * 1024 || (R == 1 && lds <= 160 * 1024)) {  // two blocks per CU; a wide map may take a whole CU's LDS
+            g.R = R; g.XH = XH; g.xl = rows / 32; g.win = win;
+            return true;
+        }
+    }
+    return false;
+}
+static int enable_gconvr(pcv_ctx* ctx) {
+    for (int dt = PCV_BF16; dt <= PCV_F16; ++dt)
+        for (int s = 1; s <= 2; ++s)
+            for (int kt = 5; kt <= 9; kt += 4)
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_gconvr(dt, s, kt)),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PCV_OK;
 }
 static int g_gconv_blocks_per_cu[3] = {2, 2, 2};
 static int enable_gconv(pcv_ctx* ctx) {
@@ -678,6 +717,7 @@ int pcv_create(pcv_ctx** out, int device) {
     int rc = enable_big_lds(ctx);
     if (rc == PCV_OK) rc = enable_d3x3(ctx);
     if (rc == PCV_OK) rc = enable_gconv(ctx);
+    if (rc == PCV_OK) rc = enable_gconvr(ctx);
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc == PCV_OK) rc = enable_mbconv(ctx);
@@ -706,6 +746,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "d1x1") ctx->use_d1x1 = value;
+    else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
@@ -809,10 +850,15 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
     else if (d->dtype == PCV_F16) pack_conv_kernel<PCV_F16><<<grid, 256, 0, s>>>(pp);
     else pack_conv_kernel<PCV_F32><<<grid, 256, 0, s>>>(pp);
     if (P.gconv) {
-        const long gtotal = (long)(d->Cin / 16) * 5 * 16 * 32;
+        const long gtotal = (long)(d->Cin / 16) * P.gconv_kt * 16 * 32;
+        const unsigned ggrid = (unsigned)((gtotal + 255) / 256);
         void* gout = static_cast<char*>(packed) + P.gconv_off;
-        if (d->dtype == PCV_BF16) pack_gconv_kernel<PCV_BF16><<<(unsigned)((gtotal + 255) / 256), 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
-        else pack_gconv_kernel<PCV_F16><<<(unsigned)((gtotal + 255) / 256), 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
+        const bool bf = d->dtype == PCV_BF16;
+        if (P.gconv_kt == 9) {
+            if (bf) pack_gconv32_kernel<PCV_BF16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin);
+            else pack_gconv32_kernel<PCV_F16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin);
+        } else if (bf) pack_gconv_kernel<PCV_BF16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
+        else pack_gconv_kernel<PCV_F16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
     }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -949,8 +995,38 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return PCV_OK;
     }
 
-    if (P.gconv && !gate && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && d->W <= 63 && cpitch == d->Cin &&
-        wpitch == d->W && M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull) {
+    const bool gconv_ok = P.gconv && !gate && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && cpitch == d->Cin &&
+                          wpitch == d->W && M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull;
+    // stride 2 (even maps) or 32 channels per group: whole output rows per tile (gconv3x3r.hpp)
+    GConvRPlan gr;
+    if (gconv_ok && ctx->use_gconvr != 0 && (d->stride_h == 2 || P.gconv_kt == 9) &&
+        plan_gconvr(d->stride_h, d->H, d->W, P.Ho, P.Wo, gr)) {
+        GConvRParams q;
+        std::memset(&q, 0, sizeof(q));
+        q.x = x; q.y = y; q.scale = scale; q.shift = shift;
+        q.w = static_cast<const char*>(packed) + P.gconv_off;
+        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
+        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
+        q.Min = d->N * d->H * d->W; q.Mout = (int)M64;
+        q.W = d->W; q.Wo = P.Wo; q.Ho = P.Ho; q.C = d->Cin;
+        q.R = gr.R; q.RWo = gr.R * P.Wo; q.XH = gr.XH; q.xl = gr.xl; q.win = gr.win;
+        q.div_wo = make_fastdiv((uint32_t)P.Wo);
+        q.div_ho = make_fastdiv((uint32_t)P.Ho);
+        const long long rows = (long long)d->N * P.Ho;
+        q.nRowTiles = (int)((rows + gr.R - 1) / gr.R);
+        const long long nT = (long long)q.nRowTiles * (d->Cin / 64);
+        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+        q.nTiles = (int)nT;
+        q.act = d->act;
+        const int lds = 2 * gr.xl * 32 * 128;
+        long long nb = block_slots(ctx, lds * 2 <= 160 * 1024 ? 2 : 1);
+        if (nb > nT) nb = nT;
+        nb = (nb + 7) / 8 * 8;
+        hipLaunchKernelGGL(pick_gconvr(d->dtype, d->stride_h, P.gconv_kt), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, q);
+        HIP_TRY(ctx, hipGetLastError());
+        return PCV_OK;
+    }
+    if (gconv_ok && d->stride_h == 1 && P.gconv_kt == 5 && d->W <= 63) {
         GConvParams q;
         std::memset(&q, 0, sizeof(q));
         q.x = x; q.y = y; q.scale = scale; q.shift = shift;

@@ -397,9 +397,15 @@ def test_stem_conv_maxpool_fused_equals_two_launches(shape, dtype, grid, cuda_de
     assert torch.equal(fused.t, two.t)
 
 
-_GCONV_SHAPES = [  # (N, C, groups, H, W): 4 / 8 / 16 channels per group, every halo width class (W <= 15, <= 31, <= 63) and beyond
+_GCONV_SHAPES = [  # (N, C, groups, H, W[, stride]): 4 / 8 / 16 channels per group, every halo width class (W <= 15, <= 31, <= 63) and beyond
     (2, 128, 32, 56, 56), (3, 256, 32, 28, 28), (2, 512, 32, 14, 14), (1, 128, 32, 5, 63), (9, 64, 16, 9, 5), (1, 64, 4, 1, 1),
     (2, 192, 24, 15, 31), (1, 128, 16, 3, 70), (5, 1024, 64, 7, 7),
+    # row-tile kernel: stride 2 (ResNeXt stages 2-4: 8 / 16 / 32 channels per group), ragged last tiles, a window that takes a whole
+    # CU's LDS (Wo = 64), 1x1 output maps; odd maps at stride 2 stay on the generic path
+    (2, 256, 32, 56, 56, 2), (3, 512, 32, 28, 28, 2), (2, 1024, 32, 14, 14, 2), (7, 128, 16, 6, 4, 2), (1, 128, 32, 2, 2, 2),
+    (3, 64, 2, 10, 6, 2), (1, 128, 8, 4, 128, 2), (2, 128, 32, 15, 15, 2), (2, 128, 4, 14, 9, 2),
+    # ... and stride 1 with 32 channels per group (stage 4), up to Wo = 64; W = 70 is beyond it
+    (5, 1024, 32, 7, 7, 1), (3, 64, 2, 20, 64, 1), (1, 64, 2, 1, 1, 1), (2, 128, 4, 9, 70, 1), (11, 64, 2, 3, 5, 1),
 ]
 
 
@@ -407,23 +413,32 @@ _GCONV_SHAPES = [  # (N, C, groups, H, W): 4 / 8 / 16 channels per group, every 
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("shape", _GCONV_SHAPES, ids=["x".join(str(v) for v in s) for s in _GCONV_SHAPES])
 def test_grouped_conv3x3_kernel_vs_oracle(shape, dtype, grid, cuda_device):
-    """gconv3x3_kernel (grouped 3x3 with 4 / 8 / 16 channels per group: halo tile staged once, K = tap pair x 16 channels) against
-    the oracle; W = 70 is wider than the halo scheme stages and must take the generic path with the same result."""
+    """gconv3x3_kernel (grouped 3x3 with 4 / 8 / 16 channels per group: halo tile staged once, K = tap pair x 16 channels) and
+    gconv3x3r_kernel (stride 2, and 32 channels per group: whole output rows per tile, K = tap x 32 channels) against the oracle and
+    against the generic implicit GEMM; W = 70 is wider than the halo schemes stage and must take the generic path with the same result."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv3x3_block
     from oracle import refnet
-    N, C, groups, H, W = shape
-    blk = conv3x3_block(in_channels=C, out_channels=C, groups=groups).eval()
+    N, C, groups, H, W = shape[:5]
+    stride = shape[5] if len(shape) > 5 else 1
+    blk = conv3x3_block(in_channels=C, out_channels=C, stride=stride, groups=groups).eval()
     sd = util.synth_state_dict(blk.state_dict(), seed=55)
     blk.load_state_dict(sd)
     blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
     x = util.synth_input(N, C, H, W, seed=56)
-    with torch.no_grad(), util.tuning(max_blocks=grid):
-        y = engine.to_nchw(blk(engine.from_nchw(x.to(cuda_device), dtype, stem=False))).cpu()
+    with torch.no_grad():
+        h = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        with util.tuning(max_blocks=grid):
+            y = engine.to_nchw(blk(h)).cpu()
+        with util.tuning(gconvr=0):
+            y_generic = engine.to_nchw(blk(h)).cpu()
     q = refnet.Quant(dtype)
-    ref = refnet.conv_block(sd, "", q.r(x), padding=1, groups=groups, q=q)
+    ref = refnet.conv_block(sd, "", q.r(x), stride=stride, padding=1, groups=groups, q=q)
+    assert y.shape == ref.shape
     d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+    d = (y - y_generic).abs()                       # same operands, another summation order: one 16-bit rounding step apart at most
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 

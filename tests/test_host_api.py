@@ -143,7 +143,14 @@ def test_packed_size_planning_is_pure_host_logic():
     assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
     # ... followed by the second blob for gconv3x3_kernel: [128 / 16 slabs][5 K-steps][16 rows][32 K] bf16
     assert n.value == 512 + 4 * 32 * 320 * 2 + 8 * 5 * 16 * 32 * 2
-    d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128, stride_h=2, stride_w=2)      # stride 2: generic layout only
+    d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128, stride_h=2, stride_w=2)      # stride 2 (gconv3x3r_kernel): the same blob
+    assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    assert n.value == 512 + 4 * 32 * 320 * 2 + 8 * 5 * 16 * 32 * 2
+    for stride in (1, 2):                        # 32 channels per group: [128 / 16 slabs][9 taps][16 rows][32 input channels]
+        d = _desc(Cin=128, Cout=128, groups=4, x_cpitch=128, stride_h=stride, stride_w=stride)
+        assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+        assert n.value == 512 + 4 * 32 * 320 * 2 + 8 * 9 * 16 * 32 * 2
+    d = _desc(Cin=128, Cout=128, groups=32, x_cpitch=128, stride_h=2, stride_w=1)      # anisotropic stride: generic layout only
     assert L.pcv_conv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
     assert n.value == 512 + 4 * 32 * 320 * 2
     # depthwise goes through its own entry point
