@@ -207,7 +207,7 @@ def rocprof_class_us(workload, klass):
     import csv
     import glob
     names = {"dense3x3": ("d3q_kernel", "false, 9>"), "depthwise": ("dwconv_kernel", "dwconv5_kernel"),
-             "grouped3x3": ("gconv3x3_kernel",), "fused_unit": ("mbw_kernel", "mbconv_kernel")}.get(klass)
+             "grouped3x3": ("gconv3x3_kernel", "gconv3x3r_kernel"), "fused_unit": ("mbw_kernel", "mbconv_kernel")}.get(klass)
     if not names:
         return None, None
     # preferred: one full-batch forward in dispatch order (tests/tools/trace_summary.py of the same rocprofv3 run) - the --stats

@@ -2,8 +2,8 @@
 
     python tests/tools/pmc_class_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <class> [skip]
 
-class: dense3x3 (d3q_kernel + igemm_conv_kernel<..., 9>), fused_unit (mbw_kernel / mbconv_kernel), depthwise (dwconv_kernel), grouped3x3 (gconv3x3_kernel: the stride-1 grouped layers,
-29 of ResNeXt-101's 33 grouped launches; the stride-2 / 32-channels-per-group ones run on the generic kernel).
+class: dense3x3 (d3q_kernel + igemm_conv_kernel<..., 9>), fused_unit (mbw_kernel / mbconv_kernel), depthwise (dwconv_kernel), grouped3x3 (gconv3x3_kernel: stride 1 with 4..16 channels
+per group, gconv3x3r_kernel: stride 2 / 32 channels per group - all 33 grouped launches of ResNeXt-101).
 Counters are reported in KB; FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes for 16 B/lane streaming
 reads - MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16 B/lane stores. The first `skip` matching launches
 (warm-up / packing forwards) are dropped. Prints one JSON object.
@@ -13,7 +13,7 @@ import csv, json, sys
 
 def pick(name, klass):
     if klass == "grouped3x3":
-        return "gconv3x3_kernel" in name
+        return "gconv3x3_kernel" in name or "gconv3x3r_kernel" in name
     if klass == "dense3x3":
         return ("d3q_kernel" in name and ", true>(D3Params)" not in name) or ("igemm_conv_kernel" in name and name.rstrip().rstrip(")").split("(")[0].rstrip().endswith(", 9>"))
     if klass == "fused_unit":

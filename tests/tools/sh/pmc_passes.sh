@@ -1,11 +1,12 @@
 # HBM traffic per launch of each workload's roofline kernel class: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over
 # eager bench runs, summarised by tests/tools/pmc_class_traffic.py into gpurun_out/pmc_<workload>.json (merge into profiles/pmc_traffic.json).
-#   bash tests/tools/sh/pmc_passes.sh            (on the GPU box, from the repo root)
+#   bash tests/tools/sh/pmc_passes.sh [workload:class:skip ...]            (on the GPU box, from the repo root)
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 # workload:class:launches of the class in one forward (the first forward of bench.py runs 8 images: skipped)
-for spec in resnet50_bs256:dense3x3:16 mobilenetv2_w1_bs512:fused_unit:10 resnext101_32x4d_bs256:grouped3x3:28; do
+SPECS=${@:-resnet50_bs256:dense3x3:16 mobilenetv2_w1_bs512:fused_unit:10 resnext101_32x4d_bs256:grouped3x3:33}
+for spec in $SPECS; do
   W=${spec%%:*}; rest=${spec#*:}; K=${rest%%:*}; SKIP=${rest##*:}
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${W}_$C -o p -- python3 $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --graph 0 > $R/gpurun_out/pmc_${W}_$C.log 2>&1
