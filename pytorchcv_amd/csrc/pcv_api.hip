@@ -1285,6 +1285,7 @@ int pcv_conv2d_maxpool_supported(const pcv_conv_desc* d, int k, int s, int p, in
     if (!d || k != 3 || s != 2 || p != 1 || ceil_mode) return 0;
     ConvPlan P;
     if (plan_conv(*d, P, false) != nullptr || !P.stem) return 0;
+    if (d->act != PCV_ACT_RELU && d->act != PCV_ACT_RELU6) return 0;     // the kernel pools packed non-negative 16-bit values
     return (d->has_residual || d->post_act != PCV_ACT_NONE || (d->y_cpitch > 0 && d->y_cpitch != d->Cout)) ? 0 : 1;
 }
 

@@ -46,10 +46,16 @@ struct StemParams {
 
 static constexpr int kStemStageBytes = 5 * 256 * 16;          // NCHW variant: 3 planes x 37 rows x 11 chunks = 1221 chunks of 16 B
 
-__device__ __forceinline__ float stem_row_shl(float v, int n) {      // value of lane fr + n of the same 16-lane row (0 past the end)
-    const int i = __builtin_bit_cast(int, v);
-    const int r = n == 1 ? __builtin_amdgcn_update_dpp(0, i, 0x101, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, i, 0x102, 0xF, 0xF, true);
-    return __builtin_bit_cast(float, r);
+// packed 16-bit values of lane fr + n of the same 16-lane row (0 past the end)
+__device__ __forceinline__ uint32_t stem_row_shl_u32(uint32_t v, int n) {
+    return (uint32_t)(n == 1 ? __builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xF, 0xF, true));
+}
+// max of two PACKED pairs of non-negative 16-bit floats (bf16 or fp16): for sign-bit-clear patterns the IEEE order is the unsigned
+// integer order (+0 < subnormals < normals < +inf < NaN), so one v_pk_max_u16 is the two float maxima, NaN-propagating like torch's
+// max_pool2d; a NaN with the sign bit set is larger still.
+__device__ __forceinline__ uint32_t stem_pkmax(uint32_t a, uint32_t b) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
 // 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 64 (padded) channels.
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         // The LDS-DMA of this tile's patch (issued one tile ago) is tracked by vmcnt only: __syncthreads() alone is a workgroup
         // fence (lgkmcnt) + barrier, and without this wait the loop had NO vmcnt wait at all - a block's later tiles could read a
         // patch whose last pieces were still in flight (seen once in ~6 full-batch forwards as a few wrong output rows).
+        // (Waiting for everything but the previous tile's output stores - a counted vmcnt - measured no faster.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // weights + this tile's patch landed; other buffer free
         if constexpr (NCHW) {
@@ -229,39 +236,41 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             // conv position of this lane: row (14 th - 1) + 4 wave + j, column (14 tw - 1) + fr; outside the conv output = -inf
             const int wo = tw * TSTEP + TORG + fr;
             const bool colok = (unsigned)wo < (unsigned)p.Wo;
-            const float NEG = -__builtin_huge_valf();
             char* const hand = smem + WBYTES + 2 * PBYTES;      // [wave 1..3][ip][lane] x 16 bytes
             u32x4 top[2];                                       // this wave's first row after the column max (for the wave above)
             u32x4 mid[2], bot[2];                               // pooled rows 2 wave (rows j = 0..2) and 2 wave + 1 (rows j = 2, 3 + next wave)
+            // The fused pool requires ReLU / ReLU6 (pcv_conv2d_maxpool_supported): outputs are >= 0 (or NaN), so round FIRST (max commutes
+            // with the monotonic rounding) and pool the PACKED pairs with integer maxima - half the DPP shifts and maxima of an fp32
+            // pool, no unpack / repack; positions outside the conv output contribute 0.
+            {
 #pragma unroll
-            for (int ip = 0; ip < 2; ++ip) {
-                float h[4][8];
+                for (int ip = 0; ip < 2; ++ip) {
+                    uint32_t h[4][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ho = th * TSTEP + TORG + 4 * wave + j;
-                    const bool ok = colok && (unsigned)ho < (unsigned)p.Ho;
-                    float v[8];
+                    for (int j = 0; j < 4; ++j) {
+                        const int ho = th * TSTEP + TORG + 4 * wave + j;
+                        const bool ok = colok && (unsigned)ho < (unsigned)p.Ho;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
+                            v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
+                        }
+                        clamp8(v, act);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t c0 = ok ? pack2<DT>(v[2 * e], v[2 * e + 1]) : 0u;
+                            h[j][e] = stem_pkmax(c0, stem_pkmax(stem_row_shl_u32(c0, 1), stem_row_shl_u32(c0, 2)));
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * ip][j][e] * sc[ip][e] + sf[ip][e];
-                        v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
+                        top[ip][e] = h[0][e];
+                        mid[ip][e] = stem_pkmax(h[0][e], stem_pkmax(h[1][e], h[2][e]));
+                        bot[ip][e] = stem_pkmax(h[2][e], h[3][e]);
                     }
-                    apply_act8(v, act);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float c0 = ok ? v[e] : NEG;
-                        // lanes fr + 1, fr + 2 of the same row; DPP returns 0 past lane 15, only fr <= 12 is used below
-                        h[j][e] = fmaxf(c0, fmaxf(stem_row_shl(c0, 1), stem_row_shl(c0, 2)));
-                    }
+                    if (wave > 0) *reinterpret_cast<u32x4*>(hand + (((wave - 1) * 2 + ip) * 64 + lane) * 16) = top[ip];
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    top[ip][e] = pack2<DT>(h[0][2 * e], h[0][2 * e + 1]);
-                    mid[ip][e] = pack2<DT>(fmaxf(h[0][2 * e], fmaxf(h[1][2 * e], h[2][2 * e])),
-                                           fmaxf(h[0][2 * e + 1], fmaxf(h[1][2 * e + 1], h[2][2 * e + 1])));
-                    bot[ip][e] = pack2<DT>(fmaxf(h[2][2 * e], h[3][2 * e]), fmaxf(h[2][2 * e + 1], h[3][2 * e + 1]));
-                }
-                if (wave > 0) *reinterpret_cast<u32x4*>(hand + (((wave - 1) * 2 + ip) * 64 + lane) * 16) = top[ip];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the hand-down rows are written; the next patch's DMA stays in flight
             __builtin_amdgcn_s_barrier();
@@ -274,12 +283,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
                 if (wave < 3) {
                     const u32x4 nx = *reinterpret_cast<const u32x4*>(hand + ((wave * 2 + ip) * 64 + lane) * 16);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a0, a1, b0, b1;
-                        unpack2<DT>(bot[ip][e], a0, a1);
-                        unpack2<DT>(nx[e], b0, b1);
-                        bot[ip][e] = pack2<DT>(fmaxf(a0, b0), fmaxf(a1, b1));
-                    }
+                    for (int e = 0; e < 4; ++e) bot[ip][e] = stem_pkmax(bot[ip][e], nx[e]);
                 }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
