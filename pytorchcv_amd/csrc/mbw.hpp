@@ -34,15 +34,16 @@ struct MbwLds {
     int wexp, wproj, wdw, bn, wave0, per_wave, total;
 };
 // 16-pixel blocks over the input window of a wave tile
-static inline __host__ __device__ int mbw_npt(int stride, int tw) {
-    const int nblk = stride == 1 ? 4 : 2, ro = nblk * (16 / tw);
+// rb: pixel blocks per wave tile (0 = the default: 4 at stride 1, 2 at stride 2)
+static inline __host__ __device__ int mbw_npt(int stride, int tw, int rb = 0) {
+    const int nblk = rb > 0 ? rb : (stride == 1 ? 4 : 2), ro = nblk * (16 / tw);
     const int iw = (tw - 1) * stride + 3, iws = iw + ((stride == 2 && tw == 8) ? 1 : 0);      // storage pitch of a window row
     return (((ro - 1) * stride + 3) * iws + 15) / 16;                                        // 7 / 7 (stride 1), 11 / 11 (stride 2)
 }
 // ka: K steps of the expand GEMM (Cin <= 32 ka). With ka == 1 the two 1x1 weight matrices live in LDS; wider units (64 -> 384 ->
 // 64 is 98 KB of weights) leave them in L2 and every wave fetches its fragments per chunk.
-static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves, int tw, int ka = 1) {
-    const int npt = mbw_npt(stride, tw), rows = stride == 1 ? 4 : 2;
+static inline __host__ __device__ MbwLds mbw_lds_layout(int stride, int nrt, int nChunks, int nWaves, int tw, int ka = 1, int rb = 0) {
+    const int npt = mbw_npt(stride, tw, rb), rows = rb > 0 ? rb : (stride == 1 ? 4 : 2);
     MbwLds L;
     int o = 0;
     const int pitch = ka == 1 ? 64 : 80;                          // (the two-K-step variant keeps unswizzled rows on an 80-byte pitch: below)
@@ -74,12 +75,15 @@ template <int ACT, int N> __device__ __forceinline__ void mbw_act(float (&v)[N],
 }
 
 // S: stride; NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise
-// stages when both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; TW: columns of a pixel block (16 or 8). Cin <= 32.
+// stages when both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; TW: columns of a pixel block (16 or 8). Cin <= 32 KA.
+// RB: pixel blocks per wave tile, 0 = 4 (stride 1) / 2 (stride 2). The WIDE units (96 projected channels = NRT 6, up to three expand
+// K steps: MobileNetV2 units 11-13, 64 / 96 -> 384 / 576 -> 96 at 14x14) run with RB = 2: 48 instead of 96 accumulator registers and
+// 5 instead of 7 window blocks of x fragments per K step keep the wave inside 256 registers (one 8-wave block per CU).
 // blockDim.x = 64 * waves.
-template <int DT, int S, int NRT, int ACT, int TW, int KA = 1>
+template <int DT, int S, int NRT, int ACT, int TW, int KA = 1, int RB = 0>
 __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int R = S == 1 ? 4 : 2;                   // pixel blocks per wave tile
+    constexpr int R = RB > 0 ? RB : (S == 1 ? 4 : 2);   // pixel blocks per wave tile
     constexpr int PR = 16 / TW;                         // output rows of a pixel block
     constexpr int RO = R * PR;                          // output rows of the tile
     constexpr int IH = (RO - 1) * S + 3, IW = (TW - 1) * S + 3;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nWaves = blockDim.x >> 6;
     constexpr bool WLDS = KA == 1;                      // 1x1 weights resident in LDS (else: fragments straight from L2)
-    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves, TW, KA);
+    const MbwLds L = mbw_lds_layout(S, NRT, p.nChunks, nWaves, TW, KA, RB);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

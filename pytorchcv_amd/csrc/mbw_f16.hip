@@ -2,3 +2,4 @@
 #include "mbw_inst.hpp"
 MBW_SHAPES(MBW_DEFINE, PCV_F16)
 MBW2_SHAPES(MBW2_DEFINE, PCV_F16)
+MBW3_SHAPES(MBW3_DEFINE, PCV_F16)

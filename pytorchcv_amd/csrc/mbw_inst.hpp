@@ -12,6 +12,12 @@
 #define MBW2_SHAPES(X, DT) \
     X(DT, 1, 4, -1, 16, 2) X(DT, 1, 4, -1, 8, 2) X(DT, 1, 4, PCV_ACT_RELU, 16, 2) X(DT, 1, 4, PCV_ACT_RELU, 8, 2) \
     X(DT, 1, 4, PCV_ACT_RELU6, 16, 2) X(DT, 1, 4, PCV_ACT_RELU6, 8, 2)
+// wide units: 96 projected channels (NRT = 6), two or three expand K steps, 2 pixel blocks per wave tile, stride 1, 1 x 16 blocks
+#define MBW3_SHAPES(X, DT) \
+    X(DT, 1, 6, -1, 16, 2, 2) X(DT, 1, 6, PCV_ACT_RELU, 16, 2, 2) X(DT, 1, 6, PCV_ACT_RELU6, 16, 2, 2) \
+    X(DT, 1, 6, -1, 16, 3, 2) X(DT, 1, 6, PCV_ACT_RELU, 16, 3, 2) X(DT, 1, 6, PCV_ACT_RELU6, 16, 3, 2)
+#define MBW3_DEFINE(DT, S, NRT, ACT, TW, KA, RB) template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA, RB>(const MbParams);
+#define MBW3_DECLARE(DT, S, NRT, ACT, TW, KA, RB) extern template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA, RB>(const MbParams);
 #define MBW2_DEFINE(DT, S, NRT, ACT, TW, KA) template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA>(const MbParams);
 #define MBW2_DECLARE(DT, S, NRT, ACT, TW, KA) extern template __global__ void mbw_kernel<DT, S, NRT, ACT, TW, KA>(const MbParams);
 

@@ -21,6 +21,8 @@ MBW_SHAPES(MBW_DECLARE, PCV_BF16)
 MBW_SHAPES(MBW_DECLARE, PCV_F16)
 MBW2_SHAPES(MBW2_DECLARE, PCV_BF16)
 MBW2_SHAPES(MBW2_DECLARE, PCV_F16)
+MBW3_SHAPES(MBW3_DECLARE, PCV_BF16)
+MBW3_SHAPES(MBW3_DECLARE, PCV_F16)
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 #include "head_gemm.hpp"
@@ -564,23 +566,24 @@ static mbconv_fn pick_mbconv(int dt, int stride, bool expand, int nrowt) {
     return nrowt <= 2 ? mbconv_for<PCV_F16, 2>(stride, expand) : mbconv_for<PCV_F16, 6>(stride, expand);
 }
 // wave-private variant (mbw.hpp): Cin <= 32, Cout <= 64
-struct MbwEntry { int dt, s, nrt, act, tw, ka; mbconv_fn fn; };
-#define MBW_ROW(DT, S, NRT, ACT, TW) {DT, S, NRT, ACT, TW, 1, mbw_kernel<DT, S, NRT, ACT, TW>},
-#define MBW2_ROW(DT, S, NRT, ACT, TW, KA) {DT, S, NRT, ACT, TW, KA, mbw_kernel<DT, S, NRT, ACT, TW, KA>},
+struct MbwEntry { int dt, s, nrt, act, tw, ka, rb; mbconv_fn fn; };
+#define MBW_ROW(DT, S, NRT, ACT, TW) {DT, S, NRT, ACT, TW, 1, 0, mbw_kernel<DT, S, NRT, ACT, TW>},
+#define MBW2_ROW(DT, S, NRT, ACT, TW, KA) {DT, S, NRT, ACT, TW, KA, 0, mbw_kernel<DT, S, NRT, ACT, TW, KA>},
+#define MBW3_ROW(DT, S, NRT, ACT, TW, KA, RB) {DT, S, NRT, ACT, TW, KA, RB, mbw_kernel<DT, S, NRT, ACT, TW, KA, RB>},
 static const MbwEntry kMbw[] = {MBW_SHAPES(MBW_ROW, PCV_BF16) MBW_SHAPES(MBW_ROW, PCV_F16) MBW2_SHAPES(MBW2_ROW, PCV_BF16)
-                                MBW2_SHAPES(MBW2_ROW, PCV_F16)};
+                                MBW2_SHAPES(MBW2_ROW, PCV_F16) MBW3_SHAPES(MBW3_ROW, PCV_BF16) MBW3_SHAPES(MBW3_ROW, PCV_F16)};
 // act: PCV_ACT_RELU / PCV_ACT_RELU6 when both inner activations are that one, anything else = the launch-time codes
-static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka) {
+static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka, int rb) {
     if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
     for (const MbwEntry& e : kMbw)
-        if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw && e.ka == ka) return e.fn;
+        if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw && e.ka == ka && e.rb == rb) return e.fn;
     return nullptr;
 }
 static const int kMbwMaxLds = 160 * 1024;
 // waves per block (one block per CU): as many of 8 / 6 / 4 as the LDS holds beside the unit's weights; 0 = does not fit
-static int mbw_waves(int stride, int nrt, int nChunks, int tw, int ka) {
+static int mbw_waves(int stride, int nrt, int nChunks, int tw, int ka, int rb) {
     for (int nw = 8; nw >= 4; nw -= 2)
-        if (mbw_lds_layout(stride, nrt, nChunks, nw, tw, ka).total <= kMbwMaxLds) return nw;
+        if (mbw_lds_layout(stride, nrt, nChunks, nw, tw, ka, rb).total <= kMbwMaxLds) return nw;
     return 0;
 }
 static const int kMbMaxLds = 150 * 1024;
@@ -606,11 +609,16 @@ static int enable_mbconv(pcv_ctx* ctx) {
 }
 // Shapes the wave-private kernel (mbw.hpp) runs: an expand convolution with one K step (Cin <= 32: any stride, <= 64 projected
 // channels, weights in LDS) or two (Cin <= 64: stride 1, <= 64 projected channels, weights stay in L2).
-static bool mbw_shape(int Cin, int Cout, int stride, int H, int W, int* ka_out, int* nrt_out) {
-    const int ka = (Cin + 31) / 32, nrt = Cout <= 32 ? 2 : 4;
+// ... or, WIDE units (pcv_set_tuning("mbw_wide", 0) = off): 65..96 projected channels with two or three K steps at stride 1, on wave
+// tiles of 2 pixel blocks (rb = 2) of 1 x 16 pixels.
+static int g_mbw_wide = 1;                                                          // process-wide: the `supported` query has no context
+static bool mbw_shape(int Cin, int Cout, int stride, int H, int W, int* ka_out, int* nrt_out, int* rb_out = nullptr) {
+    const int ka = (Cin + 31) / 32, nrt = Cout <= 32 ? 2 : (Cout <= 64 ? 4 : 6);
     if (ka_out) *ka_out = ka;
     if (nrt_out) *nrt_out = nrt;
-    if (H > 250 || W > 250 || Cout > 64) return false;
+    if (rb_out) *rb_out = nrt == 6 ? 2 : 0;
+    if (H > 250 || W > 250 || Cout > 96) return false;
+    if (nrt == 6) return g_mbw_wide != 0 && stride == 1 && (ka == 2 || ka == 3);
     return ka == 1 || (ka == 2 && stride == 1 && nrt == 4);
 }
 // de: expand 1x1 (may be null), dd: depthwise 3x3, dp: project 1x1
@@ -635,7 +643,7 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
     // 14x14 and below / wide projections, where the three separate launches are cheap and this kernel is VALU-bound
     // the wave-private kernel (mbw.hpp: at most 32 unit inputs, one expand K step) also takes 64 projected channels and 14x14 maps
     const bool wave_tiles = de && mbw_shape(de->Cin, dp.Cout, dd.stride_h, dd.H, dd.W, nullptr, nullptr);
-    if (dp.Cout > (wave_tiles ? 64 : 32)) return "fused unit only pays for narrow projections";
+    if (dp.Cout > (wave_tiles ? 96 : 32)) return "fused unit only pays for narrow projections";
     const int Ho = (dd.H - 1) / dd.stride_h + 1, Wo = (dd.W - 1) / dd.stride_w + 1;
     if (dp.N != dd.N || dp.H != Ho || dp.W != Wo) return "shapes do not chain";
     if (Wo < (wave_tiles ? 14 : 24) || Ho < 8) return "map too small for the fused unit to pay";
@@ -649,7 +657,8 @@ static const char* mbconv_unsupported(const pcv_conv_desc* de, const pcv_conv_de
     }
     int nbuf = 0;
     if (wave_tiles) {
-        if (mbw_waves(dd.stride_h, dp.Cout <= 32 ? 2 : 4, (Cmid + 31) / 32, 16, ka) == 0) return "tiles do not fit the LDS budget";
+        if (mbw_waves(dd.stride_h, dp.Cout <= 32 ? 2 : (dp.Cout <= 64 ? 4 : 6), (Cmid + 31) / 32, 16, ka, dp.Cout > 64 ? 2 : 0) == 0)
+            return "tiles do not fit the LDS budget";
     } else if (mbconv_plan(dd.stride_h, de != nullptr, ka, (Cmid + 31) / 32, (dp.Cout + 31) / 32 * 2, &nbuf).total > kMbMaxLds)
         return "weights + tiles do not fit the LDS budget";
     const long cin = de ? de->Cin : Cmid;
@@ -741,6 +750,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "persist_nk") ctx->persist_max_nk = value;
     else if (k == "tile") ctx->force_tile = value;
     else if (k == "pair_pb") ctx->pair_pb = value;
+    else if (k == "mbw_wide") g_mbw_wide = value;           // process-wide, as "wpair"
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
@@ -1790,26 +1800,27 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     if (p.nRowT > 6 || (d_exp && p.Kpad1 < 32 * p.ka) || p.Kpad2 < 32 * p.nChunks)
         return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: unexpected packed layout");
     // wave-private tiles (mbw.hpp) where the unit qualifies; pcv_set_tuning("mbw", 0) sends the shapes BOTH kernels cover to mbconv.hpp
-    int kaw = 0, nrt = 0;
-    const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt);
+    int kaw = 0, nrt = 0, rbw = 0;
+    const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt, &rbw);
     const bool block_shape = p.Cout <= 32 && p.Wo >= 24;
     if (wave_shape && (ctx->use_mbw || !block_shape)) {
         // pixel-block shape: 1 x 16 or 2 x 8 outputs, whichever covers the map with less expand work (window blocks x tiles)
-        const int nblk = S == 1 ? 4 : 2;
+        const int nblk = rbw > 0 ? rbw : (S == 1 ? 4 : 2);
         auto tiles_of = [&](int tw) { return (long)((p.Ho + nblk * (16 / tw) - 1) / (nblk * (16 / tw))) * ((p.Wo + tw - 1) / tw); };
-        int tw = mbw_npt(S, 8) * tiles_of(8) < mbw_npt(S, 16) * tiles_of(16) ? 8 : 16;
+        int tw = mbw_npt(S, 8, rbw) * tiles_of(8) < mbw_npt(S, 16, rbw) * tiles_of(16) ? 8 : 16;
         if (ctx->use_mbw == 8 || ctx->use_mbw == 16) tw = ctx->use_mbw;
-        const int nw = mbw_waves(S, nrt, p.nChunks, tw, kaw);
+        if (rbw > 0) tw = 16;                                   // the wide units are instantiated for 1 x 16 pixel blocks only
+        const int nw = mbw_waves(S, nrt, p.nChunks, tw, kaw, rbw);
         if (nw > 0) {
             const int RO = nblk * (16 / tw);
             p.tilesH = (p.Ho + RO - 1) / RO; p.tilesW = (p.Wo + tw - 1) / tw;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
-            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw, tw, kaw);
+            const MbwLds wl = mbw_lds_layout(S, nrt, p.nChunks, nw, tw, kaw, rbw);
             const long want = (nT + nw - 1) / nw;
             const unsigned gridw = (unsigned)std::min<long>(want, (long)block_slots(ctx, 1));
-            mbconv_fn fnw = pick_mbw(d_dw->dtype, S, nrt, p.act_e == p.act_d ? p.act_e : -1, tw, kaw);
+            mbconv_fn fnw = pick_mbw(d_dw->dtype, S, nrt, p.act_e == p.act_d ? p.act_e : -1, tw, kaw, rbw);
             if (!fnw) return fail(ctx, PCV_ERR_INVALID, "pcv_mbconv_fused: no kernel instantiation");
             hipLaunchKernelGGL(fnw, dim3(gridw), dim3(64 * nw), wl.total, (hipStream_t)stream, p);
             HIP_TRY(ctx, hipGetLastError());

@@ -313,6 +313,9 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
     (2, 61, 45, 32, True, 32, 1, "relu6"), (1, 112, 112, 16, True, 24, 2, "relu6"), (5, 56, 56, 24, True, 24, 1, "relu6"),
     (3, 28, 28, 32, True, 64, 2, "relu6"), (2, 14, 14, 32, True, 64, 1, "relu6"),
     (5, 14, 14, 64, True, 64, 1, "relu6"), (3, 28, 25, 40, True, 48, 1, "relu"), (2, 17, 14, 64, True, 56, 1, "hswish"),
+    # wide units (65..96 projected channels, two or three expand K steps; wave tiles of 2 pixel blocks): MobileNetV2 units 11-13
+    (3, 14, 14, 96, True, 96, 1, "relu6"), (2, 14, 14, 64, True, 96, 1, "relu6"), (2, 17, 15, 72, True, 80, 1, "relu"),
+    (1, 20, 33, 96, True, 88, 1, "hswish"),
 ]
 
 
