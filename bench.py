@@ -240,7 +240,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="resnet50_bs256", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="auto", choices=["auto", "bf16", "fp16", "fp32"],
+                    help="storage / MFMA type; auto = the family's 16-bit mode (bf16; fp16 for MobileNetV2 / V3 / EfficientNet, whose "
+                         "bf16 logits miss the north-star 1e-2 - pytorchcv_amd.engine.compute_dtype_of); the JSON line states what ran")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch (parity/debug only)")
     ap.add_argument("--graph", type=int, default=-1, help="replay the forward from a captured hipGraph (1), eager launches (0), "
@@ -287,6 +289,9 @@ def main():
         sd_cpu = synth_state_dict(net.state_dict(), seed=1234, calib=calib_for(model))
         net.load_state_dict(sd_cpu, strict=True)
     net = pytorchcv_amd.set_compute_dtype(net.to(dev), args.dtype)
+    from pytorchcv_amd import engine
+    dtype = engine.compute_dtype_of(net)               # what "auto" resolved to for this family: reported in the JSON line
+    ovf0 = engine.fp16_overflow_count(dev) if dtype == "fp16" else 0
 
     # synthetic N(0,1)-like images: 8 distinct seeded images tiled to the batch (performance is data independent)
     base = synth_input(8, seed=rank).to(dev)
@@ -338,6 +343,11 @@ def main():
     # schedules, graph lanes) equals the 8-image eager result bit for bit; a mismatch fails the run
     y_local = y[rank * batch:(rank + 1) * batch] if use_dist else y
     want = y_ref8.repeat((batch + 7) // 8, 1)[:batch]
+    if dtype == "fp16" and engine.fp16_overflow_count(dev) != ovf0:
+        print("bench.py: the fp16 range guard counted an overflow during the run", file=sys.stderr)
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(3)
     if not bool(torch.isfinite(y_local).all()) or not torch.equal(y_local, want):
         bad = int((y_local != want).any(1).sum())
         print("bench.py: {} of {} rows of the timed batch differ from the 8-image forward".format(bad, batch), file=sys.stderr)
@@ -351,7 +361,7 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f).get(args.workload)
-        if pmc is not None and (pmc.get("dtype") != args.dtype or args.batch > 0 or pmc.get("kernel_class") != klass):
+        if pmc is not None and (pmc.get("dtype") != dtype or args.batch > 0 or pmc.get("kernel_class") != klass):
             pmc = None
     except (OSError, ValueError):
         pmc = None
@@ -406,7 +416,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": dtype,
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
             "config": {"workload": args.workload, "per_gpu_batch": batch, "global_batch": world * batch,
                        "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(world),

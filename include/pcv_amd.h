@@ -28,8 +28,9 @@ extern "C" {
 #endif
 
 /* 2: pcv_conv_desc starts with struct_size and ends with y_cpitch (version 1 had neither check; a binding built against
- * another layout is refused with PCV_ERR_INVALID instead of being read past its end) */
-#define PCV_ABI_VERSION 2
+ * another layout is refused with PCV_ERR_INVALID instead of being read past its end)
+ * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count (no layout change) */
+#define PCV_ABI_VERSION 3
 
 typedef struct pcv_ctx pcv_ctx;
 
@@ -88,6 +89,21 @@ const char* pcv_last_error(const pcv_ctx* ctx);     /* ctx may be NULL: returns 
  * before pcv_create). They select among kernels / grid sizes that compute the same result; nothing in the reference
  * corresponds to them. "max_blocks" (test only) caps every persistent grid so that small inputs walk several tiles per block. */
 int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value);
+
+/* ---- fp16 range guard ----------------------------------------------------------------------------------- */
+/* With dtype PCV_F16 every kernel that rounds a result to fp16 also checks its magnitude: fp16 turns |v| >= 65520 into infinity,
+ * which the next ReLU6 / sigmoid would clamp back into range (a wrong but plausible result; bf16 and fp32 storage share fp32's
+ * exponent range and need no check). A context counts such roundings in a device word; these three calls read it IN STREAM ORDER:
+ *   pcv_fp16_guard_begin  slot (device, 4 bytes) <- the counter, before the first kernel of a forward;
+ *   pcv_fp16_guard_end    after the last one: if the counter moved since `slot`, the `count` fp32 values at y (the logits) are
+ *                         overwritten with NaN - no host synchronisation, captured into a hipGraph like any launch. A forward that
+ *                         runs concurrently with an overflowing one on the same context is poisoned too (conservative);
+ *   pcv_fp16_overflow_count  host read of the counter (synchronises `stream`): diagnostics, tests, bench.py's post-run check.
+ * Nothing in the reference corresponds to this (it computes in fp32: `net(x)`, resnet.py:333-337); it is what makes fp16 a safe
+ * default storage type for the depthwise families, where bf16 misses the 1e-2 bound. */
+int pcv_fp16_guard_begin(pcv_ctx* ctx, unsigned* slot, void* stream);
+int pcv_fp16_guard_end(pcv_ctx* ctx, const unsigned* slot, float* y, long count, void* stream);
+int pcv_fp16_overflow_count(pcv_ctx* ctx, unsigned* count, void* stream);
 
 /* ---- layout: the only NCHW-facing calls ---------------------------------------------------------------- */
 /* x: fp32 NCHW [N,C,H,W] (what callers hand to `net(x)`, resnet.py:333) -> y: NHWC [N,H,wpitch,cpitch] in dtype,

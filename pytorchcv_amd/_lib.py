@@ -24,7 +24,7 @@ class PcvError(RuntimeError):
         self.code = code
 
 
-PCV_ABI_VERSION = 2
+PCV_ABI_VERSION = 3
 
 
 class ConvDesc(ctypes.Structure):
@@ -48,6 +48,9 @@ _SIGS = {
     "pcv_destroy": (_I, [_VP]),
     "pcv_last_error": (ctypes.c_char_p, [_VP]),
     "pcv_set_tuning": (_I, [_VP, ctypes.c_char_p, _I]),
+    "pcv_fp16_guard_begin": (_I, [_VP, _VP, _VP]),
+    "pcv_fp16_guard_end": (_I, [_VP, _VP, _VP, ctypes.c_long, _VP]),
+    "pcv_fp16_overflow_count": (_I, [_VP, ctypes.POINTER(ctypes.c_uint), _VP]),
     "pcv_nchw_to_nhwc": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_nhwc_to_nchw": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_preprocess_u8": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP]),

@@ -9,7 +9,8 @@
 // output pixel x up to 8 channels; reads are coalesced along W per channel plane, pad channels/columns get zeros.
 template <int OT>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, void* __restrict__ y,
-                                                          int N, int C, int H, int W, int cpitch, int wpitch) {
+                                                          int N, int C, int H, int W, int cpitch, int wpitch,
+                                                          uint32_t* __restrict__ ovf) {
     const long pix = (long)blockIdx.x * 256 + threadIdx.x;       // over N*H*wpitch
     const long npix = (long)N * H * wpitch;
     if (pix >= npix) return;
@@ -25,6 +26,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         v[e] = (c < C && w < W) ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
     }
     const size_t eoff = (size_t)pix * cpitch + c0;
+    F16Guard<OT, false> guard;                                          // an image value beyond fp16's range
+    guard.see(v);
+    guard.commit(ovf);
     if (cpitch - c0 >= 8) {
         store8<OT>(y, eoff, v);
     } else if (cpitch - c0 == 4) {
@@ -309,9 +313,10 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ in
 template <int DT>
 __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ x, const float* __restrict__ gate,
                                                       const void* __restrict__ res, void* __restrict__ y, long total8,
-                                                      int HW, int C, int post_act) {
+                                                      int HW, int C, int post_act, uint32_t* __restrict__ ovf) {
     const int C8 = C / 8;
     const ActClamp pact = make_act(post_act);
+    F16Guard<DT, false> guard;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         const long pix = i / C8;
@@ -328,8 +333,10 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         if (post_act != PCV_ACT_NONE) apply_act8(v, pact);
+        guard.see(v);
         store8<DT>(y, (size_t)i * 8, v);
     }
+    guard.commit(ovf);
 }
 
 // y = act(x * scale[c] + shift[c]): the BatchNorm + activation in FRONT of a convolution (PreConvBlock, conv.py:776-779;
@@ -337,9 +344,10 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
 template <int DT>
 __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, void* __restrict__ y, long total8,
-                                                    int C, int xpitch, int act_code) {
+                                                    int C, int xpitch, int act_code, uint32_t* __restrict__ ovf) {
     const int C8 = C / 8;
     const ActClamp act = make_act(act_code);
+    F16Guard<DT, false> guard;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         float v[8], a[8], b[8];
@@ -349,8 +357,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x,
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * a[e] + b[e];
         apply_act8(v, act);
+        guard.see(v);
         store8<DT>(y, (size_t)i * 8, v);
     }
+    guard.commit(ovf);
 }
 
 // ---- ImageNet preprocessing: uint8 HWC image batch -> normalised network input in one pass --------------------------------
@@ -363,7 +373,7 @@ template <int OT>
 __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ x, void* __restrict__ y, int N,
                                                            int Hs, int Ws, int C, int top, int left, int H, int W, int cpitch,
                                                            int wpitch, const float* __restrict__ mean,
-                                                           const float* __restrict__ inv_std) {
+                                                           const float* __restrict__ inv_std, uint32_t* __restrict__ ovf) {
     const long pix = (long)blockIdx.x * 256 + threadIdx.x;       // over N*H*wpitch
     if (pix >= (long)N * H * wpitch) return;
     const int w = (int)(pix % wpitch);
@@ -376,6 +386,9 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
         for (int c = 0; c < C && c < 4; ++c) v[c] = ((float)src[c] * (1.f / 255.f) - mean[c]) * inv_std[c];
     }
     const size_t eoff = (size_t)pix * cpitch;
+    F16Guard<OT, false> guard;
+    guard.see(v);
+    guard.commit(ovf);
     if constexpr (OT == PCV_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y) + eoff) = (f32x4){v[0], v[1], v[2], v[3]};
     } else {
@@ -481,3 +494,13 @@ __global__ __launch_bounds__(256) void channel_interleave2_kernel(const void* __
     store8<DT>(y, (size_t)row * ypitch + c0, v);
 }
 
+
+// ---- fp16 range guard: begin / end of a guarded forward (pcv_fp16_guard_begin / _end) -----------------------------------------------
+// begin: remember the overflow counter; end: if it moved, the forward rounded something beyond fp16's range - its fp32 outputs
+// become NaN (a loud failure instead of plausible numbers; the caller reruns in bf16).
+__global__ void f16_guard_begin_kernel(const uint32_t* __restrict__ counter, uint32_t* __restrict__ slot) { *slot = *counter; }
+__global__ __launch_bounds__(256) void f16_guard_end_kernel(const uint32_t* __restrict__ counter, const uint32_t* __restrict__ slot,
+                                                           float* __restrict__ y, long count) {
+    if (*counter == *slot) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) y[i] = __builtin_nanf("");
+}

@@ -64,6 +64,7 @@ struct D3Params {
     uint32_t* dbg;          // diagnostic builds only (-DD3X3_STAMPS)
     int stride, Hin, Win;   // 1x1 mode only: output pixel (n, ho, wo) reads input pixel (n, stride ho, stride wo) of an Hin x Win map
                             // (H, W, HW, div_hw, div_w then describe the OUTPUT map)
+    uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 // In-kernel stamps (cdna_hip_programming.md section 7): a diagnostic build (-DD3X3_STAMPS) times ONE section per K-step - the
@@ -445,6 +446,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         const int chTile = t % p.nChTiles;
         const int tileP0 = (t / p.nChTiles) * BP;
         const int mBase = tileP0 + wp * 16 * PBW + fr;
+        F16Guard<DT> guard;
 #pragma unroll
         for (int ip = 0; ip < CBW / 2; ++ip) {
             const int ch0 = chTile * BM + wc * 16 * CBW + 32 * ip + 8 * fq;
@@ -479,6 +481,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                     v[2 * e + 1] += hi;
                 }
                 clampn<8>(v, pact);
+                guard.see(v);
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -487,6 +490,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
             }
         }
+        guard.commit(p.ovf);
     };
 
     zero_acc();

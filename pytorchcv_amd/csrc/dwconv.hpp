@@ -34,6 +34,7 @@ struct DwParams {
     int act, post_act;
     long total;           // N * nseg * Wo * C8
     int flags;            // tuning: bit 0 = non-temporal output stores
+    uint32_t* ovf;        // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int DT> __device__ __forceinline__ void load8(const void* base, size_t eidx, float (&v)[8]) {
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 
     int ho = ho_begin;
     int hi = hi_first;
+    F16Guard<DT, false> guard;
+    const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && act_bounded(p.act));
     while (ho < ho_end) {
         static_for<KS>([&](auto PHC) {
             constexpr int PH = decltype(PHC)::value;
@@ -275,12 +278,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
                 if (p.post_act != PCV_ACT_NONE) {
                     if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
                 }
+                if (!bounded) guard.see(v);
                 storen<DT, CPT>(p.y, eoff, v, (p.flags & 1) != 0);
                 ++ho;
                 hi += S;
             }
         });
     }
+    guard.commit(p.ovf);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -328,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
         for (int e = 0; e < NV; ++e) { sc[e] = (f32x2){a4[2 * e], a4[2 * e + 1]}; sf[e] = (f32x2){b4[2 * e], b4[2 * e + 1]}; }
     }
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+    F16Guard<DT, false> guard;
+    const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && act_bounded(p.act));
 
     const int wi0 = wo * S - p.pl;
     uint32_t coloff[KS];
@@ -408,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
                                 if (p.post_act != PCV_ACT_NONE) {
                                     if constexpr (FAST) clampn(v, pact); else apply_actn(v, pact);
                                 }
+                                if (!bounded) guard.see(v);
                                 storen<DT, CPT>(p.y, eoff, v, (p.flags & 1) != 0);
                             }
 #pragma unroll
@@ -419,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
             }
         });
     }
+    guard.commit(p.ovf);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -29,6 +29,7 @@ struct GConvParams {
     FastDiv div_hw, div_w;
     int nPixTiles, nTiles;
     int act;
+    uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int N> __device__ __forceinline__ void gconv_wait_vmcnt() {
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void gconv3x3_kernel(const GConvParams p) {
 
         // ---- epilogue: MFMA rows 4 fq + e of slab i = channels 64 cb + 16 i + 4 fq + e, pixel 16 j + fr: 8-byte stores ----------
         const int mBase = p0 + wave * (16 * PBW) + fr;
+        F16Guard<DT> guard;                            // (rows beyond M were DMA'd as zeros: finite)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = cb * 64 + 16 * i + 4 * fq;
@@ -172,10 +174,12 @@ __global__ __launch_bounds__(256, 2) void gconv3x3_kernel(const GConvParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * sc[i][e] + sf[i][e];
                 apply_actn(v, act);
+                guard.see(v);
                 u32x2 o = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
                 __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, m < p.M ? (uint32_t)((m * p.C + ch) * 2) : 0x80000000u, 0, 0);
             }
         }
+        guard.commit(p.ovf);
         if (!has_next) break;
         tile = ntile;
         xb ^= 1;

@@ -33,6 +33,7 @@ struct GConvRParams {
     FastDiv div_wo, div_ho;
     int nRowTiles, nTiles;
     int act;
+    uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int DT, int S, int KT>
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void gconv3x3r_kernel(const GConvRParams p)
         // ---- epilogue: MFMA rows 4 fq + e of slab i = channels 64 cb + 16 i + 4 fq + e, output pixel g0 Wo + ml: 8-byte stores ----
         const int m = g0 * p.Wo + ml;
         const bool ok = lvalid && m < p.Mout;
+        F16Guard<DT, false> guard;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = cb * 64 + 16 * i + 4 * fq;
@@ -178,9 +180,11 @@ __global__ __launch_bounds__(256, 2) void gconv3x3r_kernel(const GConvRParams p)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][e] * sc[i][e] + sf[i][e];
             apply_actn(v, act);
+            guard.see(v);
             u32x2 o = {pack2<DT>(v[0], v[1]), pack2<DT>(v[2], v[3])};
             __builtin_amdgcn_raw_buffer_store_b64(o, yrsrc, ok ? (uint32_t)((m * p.C + ch) * 2) : 0x80000000u, 0, 0);
         }
+        guard.commit(p.ovf, ok);                       // (a lane without an output pixel multiplies whatever its LDS rows hold)
         if (!has_next) break;
         tile = ntile;
         xb ^= 1;

@@ -63,6 +63,7 @@ struct IgemmParams {
     int wstat;              // weight-stationary persistent mode (nk == 1, one channel tile, one group-block)
     const float* gate;      // [N][Cout_total] fp32 or null: per-image channel gate applied between the activation and the residual
                             // add (SE blocks whose squeeze was taken upstream of this convolution, pcv_conv2d_gated_fused)
+    uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int DT> struct Mma;
@@ -284,6 +285,9 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
     };
 
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
+    F16Guard<OT> guard;
+    // the stored value is bounded by construction (no range check needed) when the last thing applied to it is a bounded activation
+    const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && p.gate == nullptr && act_bounded(p.act));
     zero_acc();
     TileState cur, nxt;
     setup(tile, cur);
@@ -425,6 +429,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                     }
                 }
                 apply_act8(v, pact);
+                if (!bounded) guard.see(v);
                 if constexpr (RAGGED) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
                 }
             }
         }
+        guard.commit(p.ovf);
         if (!has_next) break;
         zero_acc();
         cur = nxt;

@@ -43,6 +43,7 @@ struct MbParams {
     int tilesH, tilesW, nTiles;
     int nbufX;                // x tile buffers (2: the next tile is prefetched)
     int act_e, act_d, act_p, post;
+    uint32_t* ovf;            // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 __device__ __forceinline__ int mb_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // [0,2,3,1]
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
     }
 
     const ActClamp act_e = make_act(p.act_e), act_d = make_act(p.act_d), act_p = make_act(p.act_p), post = make_act(p.post);
+    F16Guard<DT> guard;
 
     // ---- LDS-DMA of 32 channels [c0, c0 + 32) of tile t's input window into `dst` (same slab scheme, rows = pixels) ----------
     auto dma_tile = [&](int t, char* dst, int c0) {
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
                             v[4 + e] = ea[m][1][e] * se1[e] + he1[e];
                         }
                         apply_act8(v, act_e);
+                        if (!act_bounded(p.act_e)) guard.see(v);
                         const bool ok = valid[ip] != 0;
                         u32x4 o;
 #pragma unroll
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
                     apply_actn<4>(v, act_d);
+                    if (!act_bounded(p.act_d)) guard.see(v);
                     u32x2 o;
                     o[0] = pack2<DT>(v[0], v[1]);
                     o[1] = pack2<DT>(v[2], v[3]);
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
                         }
                         apply_act8(v, post);
                     }
+                    guard.see(v);
                     u32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
             }
         }
 
+        guard.commit(p.ovf);
         if (ntile >= p.nTiles) break;
         tile = ntile;
         if constexpr (EXPAND) {

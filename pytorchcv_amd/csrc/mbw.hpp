@@ -100,6 +100,10 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     constexpr int PITCH = SWZ ? 64 : 80;
     constexpr int IWH = (IW + 1) / 2;                    // stride 2: a window row is stored as its even columns, then its odd columns
     typedef typename Mma<DT>::frag frag;
+    // VALU instructions of one S1 pixel block between two MFMA groups (BN 4 packed fma, 16 clamps, 4 packs, address / select) - the
+    // fp16 ReLU build checks the rounded range on top (F16Guard: 4 x v_max(3)_f32 + v_cmp)
+    constexpr int S1VALU = 26 + ((DT == PCV_F16 && ACT == PCV_ACT_RELU) ? 5 : 0);
+    F16Guard<DT> guard;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nWaves = blockDim.x >> 6;
     constexpr bool WLDS = KA == 1;                      // 1x1 weights resident in LDS (else: fragments straight from L2)
@@ -300,10 +304,12 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                         const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), hi);
+                        if constexpr (ACT != PCV_ACT_RELU6) guard.see(v);          // (ReLU6: bounded by construction)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
                     } else {
                         apply_act8(v, act_e);
+                        guard.see(v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = ok ? pack2<DT>(v[2 * e], v[2 * e + 1]) : 0u;
                     }
@@ -317,11 +323,11 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                     for (int m = 0; m < NPT; ++m) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 2 * KA, 0);
                         if (m > 0) {
-                            __builtin_amdgcn_sched_group_barrier(0x002, 26, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, S1VALU, 0);
                             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                         }
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x002, 26, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, S1VALU, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 }
             }
@@ -359,6 +365,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
                     mbw_act<ACT, 4>(v, act_d);
+                    if constexpr (ACT != PCV_ACT_RELU6) guard.see(v);
                     u32x2 o;
                     o[0] = pack2<DT>(v[0], v[1]);
                     o[1] = pack2<DT>(v[2], v[3]);
@@ -415,12 +422,14 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                     }
                     apply_act8(v, post);
                 }
+                guard.see(v);
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
                 __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off, 0, 0);
             }
         }
+        guard.commit(p.ovf);
 
         tile = ntile;
         if constexpr (XPRE) {

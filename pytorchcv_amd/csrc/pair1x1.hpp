@@ -51,6 +51,7 @@ struct PairParams {
     // GATE: per-image channel gate on the first convolution (an SE block run inside it), fp32 [N][256]; n = pixel / HW
     const float* gate;
     FastDiv div_hw;
+    uint32_t* ovf;            // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int N> __device__ __forceinline__ void pair_wait_vmcnt() {
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
     pair_wait_vmcnt<0>();
     bool first = true;
 
+    F16Guard<DT> guard;
     auto step = [&](auto KC) -> bool {
         constexpr int slot = decltype(KC)::value;
         constexpr int slot2 = (slot + 2) % 3;
@@ -236,10 +238,14 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
                 for (int j = 0; j < PB; ++j)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        resc[ip][j][e] = pack2<DT>(accd[2 * ip][j][2 * e] * s0[2 * e] + h0[2 * e],
-                                                   accd[2 * ip][j][2 * e + 1] * s0[2 * e + 1] + h0[2 * e + 1]);
-                        resc[ip][j][2 + e] = pack2<DT>(accd[2 * ip + 1][j][2 * e] * s1[2 * e] + h1[2 * e],
-                                                       accd[2 * ip + 1][j][2 * e + 1] * s1[2 * e + 1] + h1[2 * e + 1]);
+                        const float a0 = accd[2 * ip][j][2 * e] * s0[2 * e] + h0[2 * e];
+                        const float a1 = accd[2 * ip][j][2 * e + 1] * s0[2 * e + 1] + h0[2 * e + 1];
+                        const float b0 = accd[2 * ip + 1][j][2 * e] * s1[2 * e] + h1[2 * e];
+                        const float b1 = accd[2 * ip + 1][j][2 * e + 1] * s1[2 * e + 1] + h1[2 * e + 1];
+                        guard.see2(a0, a1);
+                        guard.see2(b0, b1);
+                        resc[ip][j][e] = pack2<DT>(a0, a1);
+                        resc[ip][j][2 + e] = pack2<DT>(b0, b1);
                     }
             }
         }
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r8[e];
                 apply_act8(v, post1);
+                guard.see(v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[ip][j][e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
             }
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
                 v[4 + e] = z[2 * k + 1][e] * sc2[k][4 + e] + sf2[k][4 + e];
             }
             apply_act8(v, act2);
+            guard.see(v);
             u32x4 q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(256, PB == 4 ? 1 : 2) void pair1x1_kernel(const Pai
             const uint32_t off = pix < p.M ? (uint32_t)((pix * C2 + 32 * ip + 8 * fq) * 2) : 0x80000000u;
             __builtin_amdgcn_raw_buffer_store_b128(q, y2rsrc, off, 0, 0);
         }
+        guard.commit(p.ovf);
         tile += tstride;
         return tile < p.nTiles;
     };

@@ -56,6 +56,8 @@ struct pcv_ctx {
                                 // tiles per block through the cross-tile pipelines (pcv_set_tuning("max_blocks", n))
     int pair_pb = 2;            // fused 1x1 pair: 16-pixel blocks per tile (2: two blocks per CU, 4: one 512-register block)
     int persist_max_nk = 4;     // auto: persistent when a tile has at most this many K-steps (PCV_AMD_PERSIST_NK)
+    uint32_t* ovf = nullptr;    // device word: how many threads have rounded a value beyond fp16's range so far (F16Guard, pcv_common.hpp);
+                                // monotonic, never reset - pcv_fp16_guard_begin / _end compare two readings of it in stream order
 };
 
 static thread_local std::string g_create_err;
@@ -730,8 +732,14 @@ int pcv_create(pcv_ctx** out, int device) {
     if (rc == PCV_OK) rc = enable_stem(ctx);
     if (rc == PCV_OK) rc = enable_pair(ctx);
     if (rc == PCV_OK) rc = enable_mbconv(ctx);
+    if (rc == PCV_OK) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->ovf), 256);
+        if (e == hipSuccess) e = hipMemset(ctx->ovf, 0, 256);
+        if (e != hipSuccess) rc = fail(ctx, PCV_ERR_HIP, std::string("pcv_create: overflow counter: ") + hipGetErrorString(e));
+    }
     if (rc != PCV_OK) {
         g_create_err = ctx->err;
+        if (ctx->ovf) (void)hipFree(ctx->ovf);
         delete ctx;
         (void)hipSetDevice(prev);
         return rc;
@@ -768,7 +776,40 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
 }
 
 int pcv_destroy(pcv_ctx* ctx) {
+    if (ctx && ctx->ovf) {
+        DeviceGuard device_guard(ctx->device);
+        (void)hipFree(ctx->ovf);
+    }
     delete ctx;
+    return PCV_OK;
+}
+
+// ---- fp16 range guard ---------------------------------------------------------------------------------------
+int pcv_fp16_guard_begin(pcv_ctx* ctx, unsigned* slot, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!slot) return fail(ctx, PCV_ERR_INVALID, "pcv_fp16_guard_begin: slot is NULL");
+    f16_guard_begin_kernel<<<1, 1, 0, (hipStream_t)stream>>>(ctx->ovf, slot);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_fp16_guard_end(pcv_ctx* ctx, const unsigned* slot, float* y, long count, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!slot || !y || count <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_fp16_guard_end: bad argument");
+    const unsigned grid = (unsigned)std::min<long>((count + 255) / 256, 1024);
+    f16_guard_end_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ctx->ovf, slot, y, count);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+int pcv_fp16_overflow_count(pcv_ctx* ctx, unsigned* count, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!count) return fail(ctx, PCV_ERR_INVALID, "pcv_fp16_overflow_count: count is NULL");
+    HIP_TRY(ctx, hipMemcpyAsync(count, ctx->ovf, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     return PCV_OK;
 }
 
@@ -784,9 +825,9 @@ int pcv_nchw_to_nhwc(pcv_ctx* ctx, const float* x, void* y, int N, int C, int H,
     const long npix = (long)N * H * wpitch;
     dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((cpitch + 7) / 8));
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == PCV_BF16) nchw_to_nhwc_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
-    else if (dtype == PCV_F16) nchw_to_nhwc_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
-    else nchw_to_nhwc_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch);
+    if (dtype == PCV_BF16) nchw_to_nhwc_kernel<PCV_BF16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch, ctx->ovf);
+    else if (dtype == PCV_F16) nchw_to_nhwc_kernel<PCV_F16><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch, ctx->ovf);
+    else nchw_to_nhwc_kernel<PCV_F32><<<grid, 256, 0, s>>>(x, y, N, C, H, W, cpitch, wpitch, ctx->ovf);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }
@@ -966,7 +1007,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_nchw_stem_fused: the fp32 image batch exceeds the 2 GiB window of one launch; split the batch");
     if (P.stem) {
         StemParams q;
-        q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift;
+        q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
         q.x_bytes = x_nchw ? (uint32_t)((unsigned long long)d->N * d->Cin * d->H * d->W * 4ull) : (uint32_t)xbytes;
         q.w_bytes = (uint32_t)P.w_bytes; q.Cin = d->Cin;
         q.Hq = pool ? pool_out(P.Ho, 3, 2, 1, 0) : P.Ho;
@@ -1013,7 +1054,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         plan_gconvr(d->stride_h, d->H, d->W, P.Ho, P.Wo, gr)) {
         GConvRParams q;
         std::memset(&q, 0, sizeof(q));
-        q.x = x; q.y = y; q.scale = scale; q.shift = shift;
+        q.x = x; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
         q.w = static_cast<const char*>(packed) + P.gconv_off;
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
         q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
@@ -1039,7 +1080,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     if (gconv_ok && d->stride_h == 1 && P.gconv_kt == 5 && d->W <= 63) {
         GConvParams q;
         std::memset(&q, 0, sizeof(q));
-        q.x = x; q.y = y; q.scale = scale; q.shift = shift;
+        q.x = x; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
         q.w = static_cast<const char*>(packed) + P.gconv_off;
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
         q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
@@ -1080,7 +1121,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         D3Params q;
         std::memset(&q, 0, sizeof(q));
         q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
-        q.scale = scale; q.shift = shift;
+        q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes3;
         q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
         q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch3;
@@ -1122,7 +1163,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         D3Params q;
         std::memset(&q, 0, sizeof(q));
         q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
-        q.scale = scale; q.shift = shift;
+        q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
         q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes1;
         q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
         q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch1;
@@ -1204,6 +1245,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.w = static_cast<const char*>(packed) + P.ktab_bytes;
     p.res = d->has_residual ? residual : nullptr;
     p.gate = gate;
+    p.ovf = ctx->ovf;
     p.y = y;
     p.scale = scale;
     p.shift = shift;
@@ -1342,6 +1384,7 @@ int pcv_dwconv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.y = y;
     p.scale = scale;
     p.shift = shift;
+    p.ovf = ctx->ovf;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin;
     const unsigned long long xbytes = (unsigned long long)d->N * d->H * d->W * d->Cin * esize(d->dtype);
     if (xbytes >= 0x80000000ull)
@@ -1497,9 +1540,9 @@ int pcv_se_scale(pcv_ctx* ctx, const void* x, const float* gate, const void* res
     // blocks read 4.4 (tests/tools/micro/copy_bw2.cpp); the cap only exists for the multi-round tests (max_blocks)
     if (ctx->max_blocks > 0 && blocks > ctx->max_blocks) blocks = ctx->max_blocks;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
-    else if (dtype == PCV_F16) se_scale_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
-    else se_scale_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act);
+    if (dtype == PCV_BF16) se_scale_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act, ctx->ovf);
+    else if (dtype == PCV_F16) se_scale_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act, ctx->ovf);
+    else se_scale_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, gate, residual, y, total8, HW, C, post_act, ctx->ovf);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }
@@ -1558,7 +1601,7 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
             return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
         WPairParams q;
         std::memset(&q, 0, sizeof(q));
-        q.x = x; q.res = residual; q.y1 = y1; q.y2 = y2;
+        q.x = x; q.res = residual; q.y1 = y1; q.y2 = y2; q.ovf = ctx->ovf;
         q.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
         q.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
         q.scale1 = scale1; q.shift1 = shift1; q.scale2 = scale2; q.shift2 = shift2;
@@ -1579,7 +1622,7 @@ static int pair_impl(pcv_ctx* ctx, const pcv_conv_desc* d1, const pcv_conv_desc*
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv1x1_pair_fused: unexpected packed layout");
     PairParams p;
     std::memset(&p, 0, sizeof(p));
-    p.x = x; p.res = residual; p.y1 = y1; p.y2 = y2;
+    p.x = x; p.res = residual; p.y1 = y1; p.y2 = y2; p.ovf = ctx->ovf;
     p.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
     p.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
     p.scale1 = scale1; p.shift1 = shift1; p.scale2 = scale2; p.shift2 = shift2;
@@ -1650,7 +1693,7 @@ int pcv_conv1x1_pair_idconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_id, const
     PairParams p;
     std::memset(&p, 0, sizeof(p));
     const long M = (long)d1->N * d1->H * d1->W;
-    p.x = x; p.res = nullptr; p.y1 = y1; p.y2 = y2; p.x0 = x0;
+    p.x = x; p.res = nullptr; p.y1 = y1; p.y2 = y2; p.x0 = x0; p.ovf = ctx->ovf;
     p.w1 = static_cast<const char*>(packed1) + P1.ktab_bytes;
     p.w2 = static_cast<const char*>(packed2) + P2.ktab_bytes;
     p.wid = static_cast<const char*>(packed_id) + Pi.ktab_bytes;
@@ -1743,9 +1786,9 @@ int pcv_preprocess_u8(pcv_ctx* ctx, const unsigned char* x, void* y, int N, int 
     const long total = (long)N * H * wpitch;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PCV_BF16) preprocess_u8_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
-    else if (dtype == PCV_F16) preprocess_u8_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
-    else preprocess_u8_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std);
+    if (dtype == PCV_BF16) preprocess_u8_kernel<PCV_BF16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std, ctx->ovf);
+    else if (dtype == PCV_F16) preprocess_u8_kernel<PCV_F16><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std, ctx->ovf);
+    else preprocess_u8_kernel<PCV_F32><<<grid, 256, 0, st>>>(x, y, N, Hs, Ws, C, top, left, H, W, 4, wpitch, mean, inv_std, ctx->ovf);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }
@@ -1777,7 +1820,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     MbParams p;
     std::memset(&p, 0, sizeof(p));
     const int S = d_dw->stride_h;
-    p.x = x; p.res = d_proj->has_residual ? residual : nullptr; p.y = y;
+    p.x = x; p.res = d_proj->has_residual ? residual : nullptr; p.y = y; p.ovf = ctx->ovf;
     p.w_exp = d_exp ? static_cast<const char*>(packed_exp) + Pe.ktab_bytes : nullptr;
     p.w_dw = packed_dw;
     p.w_proj = static_cast<const char*>(packed_proj) + Pp.ktab_bytes;
@@ -1850,9 +1893,9 @@ int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shi
     long blocks = (total8 + 255) / 256;
     if (ctx->max_blocks > 0 && blocks > ctx->max_blocks) blocks = ctx->max_blocks;       // (see pcv_se_scale)
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
-    else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
-    else bn_act_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act);
+    if (dtype == PCV_BF16) bn_act_kernel<PCV_BF16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act, ctx->ovf);
+    else if (dtype == PCV_F16) bn_act_kernel<PCV_F16><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act, ctx->ovf);
+    else bn_act_kernel<PCV_F32><<<(unsigned)blocks, 256, 0, st>>>(x, scale, shift, y, total8, C, x_cpitch, act, ctx->ovf);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }

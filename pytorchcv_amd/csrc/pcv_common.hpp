@@ -64,6 +64,53 @@ template <int DT> __device__ __forceinline__ void store_elem(void* base, size_t 
     else reinterpret_cast<_Float16*>(base)[idx] = (_Float16)v;
 }
 
+// ---- fp16 range guard ------------------------------------------------------------------------------------
+// fp16 storage rounds |v| >= 65520 to infinity, and a ReLU6 / sigmoid / h-sigmoid behind it clamps that infinity back into
+// range: an overflow inside a net would come out as plausible finite logits. So every kernel that rounds fp32 results to fp16
+// checks the magnitudes it rounds (one v_max3_f32 per two values + one compare per group; NaNs are ignored - they propagate by
+// themselves) and bumps the context's overflow counter when one crossed fp16's range. pcv_fp16_guard_begin / _end
+// (include/pcv_amd.h) turn a counter change during a forward into NaN logits. Compiled out for bf16 / fp32 storage.
+//   UNIFORM (the MFMA kernels, whose epilogues run in wave-uniform control flow): the verdict of a group is a wave ballot OR-ed
+//   into a scalar register pair - no vector register lives across the kernel's loops (a per-lane running maximum spilled 140-320
+//   bytes in the register-bound fused-unit kernels).
+//   !UNIFORM (per-thread loops with divergent trip counts: depthwise, elementwise): a per-lane running maximum.
+constexpr float kF16Overflow = 65520.f;
+template <int OT, bool UNIFORM = true> struct F16Guard {
+    float m;
+    unsigned long long hit;
+    __device__ __forceinline__ F16Guard() : m(0.f), hit(0ull) {}
+    __device__ __forceinline__ void note(float t) {
+        if constexpr (UNIFORM) hit |= __builtin_amdgcn_ballot_w64(t >= kF16Overflow);
+        else m = fmaxf(m, t);
+    }
+    __device__ __forceinline__ void see2(float a, float b) {
+        if constexpr (OT == PCV_F16) note(fmaxf(fabsf(a), fabsf(b)));
+    }
+    template <int N> __device__ __forceinline__ void see(const float (&v)[N]) {
+        static_assert(N % 2 == 0, "pairs");
+        if constexpr (OT == PCV_F16) {
+            float t = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+            for (int e = 2; e < N; e += 2) t = fmaxf(fmaxf(fabsf(v[e]), fabsf(v[e + 1])), t);
+            note(t);
+        }
+    }
+    // `live` (!UNIFORM only): false for a lane whose values are never stored and may be garbage
+    __device__ __forceinline__ void commit(uint32_t* counter, bool live = true) {
+        if constexpr (OT == PCV_F16) {
+            if constexpr (UNIFORM) {
+                if (hit != 0ull && counter != nullptr) {
+                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(counter, 1u);
+                }
+                hit = 0ull;
+            } else {
+                if (live && m >= kF16Overflow && counter != nullptr) atomicAdd(counter, 1u);
+                m = 0.f;
+            }
+        }
+    }
+};
+
 // ---- activations (reference: pytorchcv/models/common/activ.py) ------------------------------------------
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -85,6 +132,8 @@ struct ActClamp {
     bool slow;
     int code;
 };
+// true when a value that went through `act` (and nothing unbounded after it) lies in [0, 6]: the fp16 range check is skipped
+__device__ __forceinline__ bool act_bounded(int act) { return act == PCV_ACT_RELU6 || act == PCV_ACT_SIGMOID || act == PCV_ACT_HSIGMOID; }
 __device__ __forceinline__ ActClamp make_act(int act) {
     ActClamp a;
     a.code = act;

@@ -42,6 +42,7 @@ struct StemParams {
     int act;
     int Hq, Wq;               // POOL: pooled output size; y is [N, Hq, Wq, Cout]
     int Cin;                  // NCHW variant: planes of x (<= 3); x is fp32 [N, Cin, H, W] with W % 4 == 0, x_bytes its size
+    uint32_t* ovf;            // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 static constexpr int kStemStageBytes = 5 * 256 * 16;          // NCHW variant: 3 planes x 37 rows x 11 chunks = 1221 chunks of 16 B
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(dst0 + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
         }
     };
+    F16Guard<DT> guard;
     // NCHW: staged fp32 planes of tile t -> the 16-bit NHWC4 patch (buffer 0): item c = 256 j + tid = (patch row, pixel pair)
     auto convert_patch = [&](int t) {
         const int tw = t % p.tilesW;
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             // (a chunk is wholly inside or wholly outside the image - W % 4 == 0 - and outside chunks were DMA'd as zeros; the
             // limit only matters for the alignment columns of a chunk that straddles nothing: kept for clarity of intent)
             const bool in0 = col < Wlim, in1 = col + 1 < Wlim;
+            guard.see(v[0]);
+            guard.see(v[1]);
             u32x4 o;
             o[0] = in0 ? pack2<DT>(v[0][0], v[0][1]) : 0u;
             o[1] = in0 ? pack2<DT>(v[0][2], v[0][3]) : 0u;
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
                             v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
                         }
                         clamp8(v, act);
+                        if (!act_bounded(p.act)) guard.see(v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t c0 = ok ? pack2<DT>(v[2 * e], v[2 * e + 1]) : 0u;
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
                     v[4 + e] = acc[2 * ip + 1][j][e] * sc[ip][4 + e] + sf[ip][4 + e];
                 }
                 apply_act8(v, act);
+                if (!act_bounded(p.act)) guard.see(v);
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             }
         }
         }
+        guard.commit(p.ovf);
         if (!has_next) break;
         tile = ntile;
         buf ^= 1;

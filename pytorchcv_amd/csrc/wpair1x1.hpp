@@ -49,6 +49,7 @@ struct WPairParams {
     const float* gate;
     FastDiv div_hw;
     uint32_t hw;
+    uint32_t* ovf;            // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
 template <int N> __device__ __forceinline__ void wpair_wait_vmcnt() {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
 
             // ---- epilogue 1: BN, + residual, activation, round; the packs are GEMM2's B fragments ---------------------------
             u32x4 o[NIP][PBW];
+            F16Guard<DT> guard;
 #pragma unroll
             for (int ipl = 0; ipl < NIP; ++ipl) {
                 const int ch = 64 * c + 32 * (NIP * wc + ipl) + 8 * fq;
@@ -282,10 +284,12 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r8[e];
                     apply_act8(v, post1);
+                    guard.see(v);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[ipl][j][e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
                 }
             }
+            guard.commit(p.ovf);
 #pragma unroll
             for (int ipl = 0; ipl < NIP; ++ipl)
 #pragma unroll
@@ -338,6 +342,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
         }
 
         // ---- epilogue 2: pixels 16 j + fr, channels 32 ip + 8 fq .. +8, ip = (NI2W / 2) wc .. -------------------------------------
+        F16Guard<DT> guard2;
 #pragma unroll
         for (int ipl = 0; ipl < NI2W / 2; ++ipl) {
             const int ch = 32 * ((NI2W / 2) * wc + ipl) + 8 * fq;
@@ -352,6 +357,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
                     v[4 + e] = acc2[2 * ipl + 1][j][e] * s1[e] + h1[e];
                 }
                 apply_act8(v, act2);
+                guard2.see(v);
                 u32x4 q;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) q[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -360,6 +366,7 @@ __global__ __launch_bounds__((64 * WPairCfg<CM, C1_>::NW), 2) void wpair1x1_kern
                 __builtin_amdgcn_raw_buffer_store_b128(q, y2rsrc, off, 0, 0);
             }
         }
+        guard2.commit(p.ovf);
         tile += tstride;
         tile_parity = !tile_parity;
         if (tile >= p.nTiles) break;

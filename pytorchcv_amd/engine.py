@@ -4,7 +4,7 @@
     PyTorch is used for device memory and streams only.
 """
 
-__all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'from_nchw', 'to_nchw', 'ConvRunner',
+__all__ = ['NHWC', 'DTYPES', 'default_dtype', 'set_compute_dtype', 'compute_dtype_of', 'Fp16Guard', 'fp16_overflow_count', 'from_nchw', 'to_nchw', 'ConvRunner',
            'BnActRunner', 'maxpool2d', 'avgpool2d', 'global_avgpool', 'se_forward', 'channel_slice', 'cat_shuffle2', 'act_code',
            'boundary', 'round8', 'channel_concat_into', 'interpolate', 'add']
 
@@ -22,23 +22,64 @@ _NAME_OF_TORCH = {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: 
 
 
 def default_dtype() -> str:
-    d = os.environ.get("PCV_AMD_DTYPE", "bf16")
-    if d not in DTYPES:
-        raise ValueError("PCV_AMD_DTYPE must be one of {}".format(sorted(DTYPES)))
+    """Process-wide storage / MFMA type of the hot path (env PCV_AMD_DTYPE): "auto" (default), "bf16", "fp16" or "fp32"."""
+    d = os.environ.get("PCV_AMD_DTYPE", "auto")
+    if d not in DTYPES and d != "auto":
+        raise ValueError("PCV_AMD_DTYPE must be one of {}".format(sorted(DTYPES) + ["auto"]))
     return d
 
 
 def set_compute_dtype(net: nn.Module, dtype: str) -> nn.Module:
-    """Select the storage/MFMA type of the hot path for `net`: "bf16" (default), "fp16" or "fp32"."""
-    if dtype not in DTYPES:
-        raise ValueError("dtype must be one of {}".format(sorted(DTYPES)))
+    """Select the storage/MFMA type of the hot path for `net`: "auto" (default: the family's 16-bit mode, see
+    `compute_dtype_of`), "bf16", "fp16" or "fp32"."""
+    if dtype not in DTYPES and dtype != "auto":
+        raise ValueError("dtype must be one of {}".format(sorted(DTYPES) + ["auto"]))
     for m in net.modules():
         m._pcv_dtype = dtype
     return net
 
 
 def compute_dtype_of(module: nn.Module) -> str:
-    return getattr(module, "_pcv_dtype", None) or default_dtype()
+    """The type `module` runs in. "auto" resolves to the module's own 16-bit mode: bf16, except for the net classes that declare
+    `pcv_16bit = "fp16"` - the depthwise-separable families (MobileNetV2 / V3, EfficientNet), whose logits stay within the
+    north-star 1e-2 of the reference's fp32 forward in fp16 (2e-3 .. 5e-3) but not in bf16 (1.3e-2 .. 2.2e-2: 8 mantissa bits on
+    weights that multiply [0, 6]-bounded activations). Same MFMA rate, same bytes; fp16's narrower exponent
+    range is covered by the range guard (`Fp16Guard`)."""
+    d = getattr(module, "_pcv_dtype", None) or default_dtype()
+    if d == "auto":
+        d = getattr(module, "pcv_16bit", None) or "bf16"
+    return d
+
+
+class Fp16Guard(object):
+    """fp16 range guard around one forward (include/pcv_amd.h, pcv_fp16_guard_begin / _end): every kernel counts the values it
+    rounds beyond fp16's range; `finish(y)` - stream-ordered, no host synchronisation, capturable - overwrites the fp32 result `y`
+    with NaN when the count moved during the forward. A no-op for bf16 / fp32."""
+    __slots__ = ("slot", "device")
+
+    def __init__(self, device, torch_dtype):
+        self.slot = None
+        self.device = device
+        if torch_dtype == torch.float16:
+            self.slot = torch.empty(1, dtype=torch.int32, device=device)
+            ctx = _ctx(device)
+            _lib.check(_lib.lib().pcv_fp16_guard_begin(ctx, _ptr(self.slot), _stream(device)), ctx)
+
+    def finish(self, y: torch.Tensor) -> torch.Tensor:
+        if self.slot is not None:
+            if y.dtype != torch.float32 or not y.is_contiguous():
+                raise RuntimeError("the fp16 guard poisons a contiguous fp32 result")
+            ctx = _ctx(self.device)
+            _lib.check(_lib.lib().pcv_fp16_guard_end(ctx, _ptr(self.slot), _ptr(y), y.numel(), _stream(self.device)), ctx)
+        return y
+
+
+def fp16_overflow_count(device) -> int:
+    """How many threads of this device's context have rounded a value beyond fp16's range so far (synchronises the stream)."""
+    ctx = _ctx(device)
+    n = ctypes.c_uint(0)
+    _lib.check(_lib.lib().pcv_fp16_overflow_count(ctx, ctypes.byref(n), _stream(device)), ctx)
+    return int(n.value)
 
 
 def round8(c: int) -> int:
@@ -176,8 +217,11 @@ def boundary(module: nn.Module, x, fn, stem: bool = False):
         return fn(x)
     if not torch.is_tensor(x):
         raise TypeError("expected a torch.Tensor or an NHWC handle")
-    y = fn(from_nchw(x, compute_dtype_of(module), stem=stem))
-    return to_nchw(y) if isinstance(y, NHWC) else y
+    dtype = compute_dtype_of(module)
+    guard = Fp16Guard(x.device, DTYPES[dtype][1])
+    y = fn(from_nchw(x, dtype, stem=stem))
+    y = to_nchw(y) if isinstance(y, NHWC) else y
+    return guard.finish(y) if torch.is_tensor(y) and y.dtype == torch.float32 else y
 
 
 def act_code(activ) -> int:

@@ -96,11 +96,14 @@ def run_net(net: nn.Module, x, head, stem: bool = True):
     has stride 2 and takes the image in the 4-channel-padded stem layout (engine.from_nchw)."""
     check_channels(net)
     if isinstance(x, engine.NHWC):
-        return head(net.features(x))
+        guard = engine.Fp16Guard(x.device, x.dtype)
+        return guard.finish(head(net.features(x)))
     if not torch.is_tensor(x) or x.dim() != 4:
         raise TypeError("expected an NCHW tensor")
-    a = engine.network_input(x, engine.compute_dtype_of(net)) if stem else engine.from_nchw(x, engine.compute_dtype_of(net), stem=False)
-    return head(net.features(a))
+    dtype = engine.compute_dtype_of(net)
+    guard = engine.Fp16Guard(x.device, engine.DTYPES[dtype][1])      # fp16 only: overflow -> NaN logits, never plausible ones
+    a = engine.network_input(x, dtype) if stem else engine.from_nchw(x, dtype, stem=False)
+    return guard.finish(head(net.features(a)))
 
 
 def init_conv_params(net: nn.Module):

@@ -104,6 +104,8 @@ class EffiInitBlock(nn.Module):
 
 
 class EfficientNet(nn.Module):
+    pcv_16bit = "fp16"      # the 16-bit mode "auto" resolves to for this family (engine.compute_dtype_of)
+
     def __init__(self, channels, init_block_channels, final_block_channels, kernel_sizes, strides_per_stage,
                  expansion_factors, dropout_rate=0.2, tf_mode=False, bn_eps=1e-5, in_channels=3, in_size=(224, 224),
                  num_classes=1000):

@@ -38,6 +38,8 @@ class LinearBottleneck(nn.Module):
 
 
 class MobileNetV2(ClassifierNet):
+    pcv_16bit = "fp16"      # the 16-bit mode "auto" resolves to for this family (engine.compute_dtype_of)
+
     def __init__(self, channels, init_block_channels, final_block_channels, remove_exp_conv, in_channels=3,
                  in_size=(224, 224), num_classes=1000):
         super(MobileNetV2, self).__init__(in_size, num_classes)

@@ -87,6 +87,8 @@ class MobileNetV3Classifier(nn.Module):
 
 
 class MobileNetV3(nn.Module):
+    pcv_16bit = "fp16"      # the 16-bit mode "auto" resolves to for this family (engine.compute_dtype_of)
+
     def __init__(self, channels, exp_channels, init_block_channels, final_block_channels, classifier_mid_channels, kernels3,
                  use_relu, use_se, first_stride, final_use_se, in_channels=3, in_size=(224, 224), num_classes=1000):
         super(MobileNetV3, self).__init__()

@@ -3,12 +3,12 @@ GPU parity, whole nets: `get_model(name)` + the fixture weights, forward through
 golden logits of the imported reference and the oracle.
 
   fp32       : |logits - golden| <= 1e-3, top-1 identical                     (north-star fp32 bound)
-  bf16, fp16 : |logits - quantisation-matched oracle| <= 1e-2, top-1 identical;
-               AND against the fp32 golden of the imported reference itself: top-1 identical, max |d| <= 1e-2 (the north-star
-               16-bit bound) for fp16 on every net and for bf16 on the nets of BASELINE configs 2 and 4 and the other
-               ResNet-family fixtures - with the fp32 head (engine.FP32_HEAD) - and <= the measured value + 10 % on the
-               depthwise nets, where rounding the WEIGHTS to 8 mantissa bits alone leaves 1.05e-2 (tests/tools/bf16_drift.py:
-               per-source attribution).
+  16 bit     : the north-star bound - max |logits - fp32 golden of the imported reference| <= 1e-2, top-1 identical - is asserted
+               as a literal 1e-2 for EVERY fixture net in the mode it runs in by default ("auto": bf16, or fp16 for the
+               depthwise-separable families - engine.compute_dtype_of) and for fp16 on every net;
+  bf16, fp16 : |logits - quantisation-matched oracle| <= 1e-2, top-1 identical to the oracle's and the reference's, on every
+               net in both types (kernel correctness; a family's non-default 16-bit type is held to this bound only:
+               DESIGN.md section 3 has the attribution of bf16's 1.3e-2 .. 2.2e-2 on the depthwise nets).
 """
 
 import pytest
@@ -18,11 +18,12 @@ from oracle import refnet
 
 pytestmark = pytest.mark.gpu
 
-# max |bf16 logits - fp32 reference golden| allowed per fixture net: 1e-2 where the north-star bound is met, else measured + 10 %
-# (measured on MI355X with the fp32 head: mobilenetv2_w1 1.55e-2, mobilenetv3 large / small 2.19e-2 / 2.15e-2, efficientnet b0 / b0b
-# 1.27e-2 / 1.30e-2; every other fixture net 4.1e-3 .. 8.6e-3)
-_BF16_VS_GOLDEN = {"mobilenetv2_w1": 1.7e-2, "mobilenetv3_large_w1": 2.4e-2, "mobilenetv3_small_w1": 2.4e-2, "efficientnet_b0": 1.4e-2,
-                   "efficientnet_b0b": 1.45e-2}
+NORTH_STAR_16BIT = 1e-2          # BASELINE.json north_star: "within ... 1e-2 (bf16)" of the reference forward
+_FP16_FAMILIES = ("mobilenetv2", "mobilenetv3", "efficientnet")
+
+
+def _auto_dtype(name):
+    return "fp16" if name.startswith(_FP16_FAMILIES) else "bf16"
 
 
 def _net(name, dtype, dev):
@@ -30,7 +31,31 @@ def _net(name, dtype, dev):
     from pytorchcv_amd.model_provider import get_model
     net = get_model(name).eval()
     net.load_state_dict(util.model_state(name, net.state_dict()), strict=True)
-    return pytorchcv_amd.set_compute_dtype(net.to(dev), dtype)
+    net = net.to(dev)
+    return net if dtype is None else pytorchcv_amd.set_compute_dtype(net, dtype)
+
+
+@pytest.mark.parametrize("name", util.MODELS)
+def test_model_default_mode_within_north_star_bound(name, cuda_device, monkeypatch):
+    """`get_model(name)` as a user gets it - no dtype chosen anywhere - against the fp32 golden of the imported reference
+    (reference forward: e.g. pytorchcv/models/mobilenetv2.py:152-156, resnet.py:333-337): max |d| <= 1e-2, top-1 identical,
+    no fp16 overflow counted."""
+    from pytorchcv_amd import engine
+    monkeypatch.delenv("PCV_AMD_DTYPE", raising=False)
+    logits, ids = util.model_golden(name)
+    net = _net(name, None, cuda_device)
+    assert engine.compute_dtype_of(net) == _auto_dtype(name)
+    before = engine.fp16_overflow_count(cuda_device)
+    with torch.no_grad():
+        y = net(util.images(ids).to(cuda_device))
+    torch.cuda.synchronize()
+    assert engine.fp16_overflow_count(cuda_device) == before
+    y = y.cpu()
+    raw = float((y - logits).abs().max())
+    print("{} default ({}): vs fp32 golden {:.3e}".format(name, _auto_dtype(name), raw))
+    assert bool(torch.isfinite(y).all())
+    assert torch.equal(y.argmax(1), logits.argmax(1)), "top-1 differs from the reference forward"
+    assert raw <= NORTH_STAR_16BIT, "{}: max |d| vs the fp32 reference golden {:.3e} > 1e-2".format(name, raw)
 
 
 @pytest.mark.parametrize("name", util.MODELS)
@@ -67,8 +92,8 @@ def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_devic
     assert err <= 1e-2
     assert torch.equal(y.argmax(1), ref.argmax(1))
     assert torch.equal(y.argmax(1), logits.argmax(1)), "top-1 differs from the reference forward"
-    bound = 1e-2 if dtype == "fp16" else _BF16_VS_GOLDEN.get(name, 1e-2)
-    assert raw <= bound, "{} {}: max |d| vs the fp32 reference golden {:.3e} > {:.1e}".format(name, dtype, raw, bound)
+    if dtype == "fp16" or dtype == _auto_dtype(name):
+        assert raw <= NORTH_STAR_16BIT, "{} {}: max |d| vs the fp32 reference golden {:.3e} > 1e-2".format(name, dtype, raw)
 
 
 # BASELINE.json configs 2-4 (+ resnet18 at the same batch): the batches bench.py times. At these sizes every persistent kernel
@@ -84,7 +109,7 @@ def test_headline_batch_matches_fixture(name, batch, cuda_device):
     Reference behaviour: net(x) at any batch, pytorchcv/models/resnet.py:333-337."""
     from pytorchcv_amd.graph import capture
     logits, ids = util.model_golden(name)
-    net = _net(name, "bf16", cuda_device)
+    net = _net(name, "auto", cuda_device)               # the mode bench.py times: bf16, MobileNetV2 fp16
     x4 = util.images(ids).to(cuda_device)
     with torch.no_grad():
         y4 = net(x4).clone()
@@ -213,7 +238,7 @@ def test_graph_batch_lanes_equal_single_lane(model, lanes, cuda_device):
     """The batch cut into independent graph branches (the kernels of one slice fill the tile-schedule tails of the other's):
     same logits, bit for bit, as the one-branch graph and as eager - also when the batch does not divide evenly."""
     from pytorchcv_amd.graph import capture
-    net = _net(model, "bf16", cuda_device)
+    net = _net(model, "auto", cuda_device)
     x = util.synth_input(7, seed=21).to(cuda_device)
     with torch.no_grad():
         y_eager = net(x).clone()
