@@ -256,6 +256,8 @@ class ConvRunner(object):
     def __init__(self, conv: nn.Conv2d, bn, pad4=None):
         self.conv, self.bn, self.pad4 = conv, bn, pad4
         self._key = None
+        self._foreign = False       # packed / scale / shift were RECEIVED (parallel.broadcast_packed_state): the local fp32 sources
+                                    # are not what they were derived from, so nothing may be re-derived from them
         self.packed = self.scale = self.shift = None
         self.depthwise = (conv.groups > 1 and conv.groups == conv.in_channels == conv.out_channels)
         if 1 < conv.groups and not self.depthwise and (conv.in_channels % 8 or conv.out_channels % 8):
@@ -313,6 +315,15 @@ class ConvRunner(object):
         key = self._state_key(x.dtype, x.cpitch, d)
         if key == self._key:
             return
+        if self._foreign:
+            # the packed state came from another rank; a new key (another dtype / channel pitch / padding parity / output type, or
+            # touched parameters) would re-pack from THIS rank's fp32 tensors, which broadcast_packed_state never updated: wrong
+            # logits with no error. Refuse; the caller re-synchronises the fp32 state first.
+            raise RuntimeError(
+                "this convolution's packed weights were received by parallel.broadcast_packed_state and would have to be re-packed "
+                "(the input's dtype / channel pitch / padding parity or a parameter changed), but this rank's fp32 parameters are "
+                "not the source's. Call parallel.broadcast_module_state(net) (or load_state_dict on every rank) before running "
+                "another configuration.")
         dev = x.device
         w = self.conv.weight
         if w.device != dev:
@@ -356,6 +367,17 @@ class ConvRunner(object):
                                      _ptr(shift), st), ctx)
         torch.cuda.current_stream(dev).synchronize()      # w32 & friends are temporaries; load-time only
         self.packed, self.scale, self.shift, self._key = packed, scale, shift, key
+
+    def adopt_foreign_state(self):
+        """Called after packed / scale / shift were overwritten with another rank's (parallel.broadcast_packed_state): the
+        cache key stays valid for exactly the configuration it was built for, anything else raises in prepare()."""
+        self._foreign = True
+        self._sq_key = None
+
+    def local_state_restored(self):
+        """The fp32 sources are authoritative again (parallel.broadcast_module_state, load_state_dict): re-pack on next use."""
+        self._foreign = False
+        self._key = None
 
     def run(self, x: NHWC, act=0, residual: NHWC | None = None, post_act=0, out_fp32=False, pad4=None, out=None, gate=None) -> NHWC:
         """`pad4`: explicit (left, right, top, bottom) zero padding for this call (the `F.pad` a unit applies in front of
@@ -723,6 +745,7 @@ class BnActRunner(object):
     def __init__(self, bn):
         self.bn = bn
         self._key = None
+        self._foreign = False       # see ConvRunner._foreign
         self.scale = self.shift = None
 
     def _state_key(self):
@@ -733,6 +756,9 @@ class BnActRunner(object):
         key = self._state_key()
         if key == self._key:
             return
+        if self._foreign:
+            raise RuntimeError("this BatchNorm's folded constants were received by parallel.broadcast_packed_state and its local "
+                               "parameters changed: call parallel.broadcast_module_state(net) first")
         bn, dev = self.bn, x.device
         if not isinstance(bn, nn.BatchNorm2d):
             raise NotImplementedError("only BatchNorm2d folds to scale/shift, got {}".format(type(bn).__name__))
@@ -755,6 +781,13 @@ class BnActRunner(object):
                                  _ptr(shift), st), ctx)
         torch.cuda.current_stream(dev).synchronize()
         self.scale, self.shift, self._key = scale, shift, key
+
+    def adopt_foreign_state(self):
+        self._foreign = True
+
+    def local_state_restored(self):
+        self._foreign = False
+        self._key = None
 
     def run(self, x: NHWC, act: int) -> NHWC:
         if self.bn.training:

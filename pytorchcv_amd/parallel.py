@@ -13,7 +13,7 @@
     The compute callable is injected, so the same plumbing is exercised on CPU with gloo in the tests.
 """
 
-__all__ = ['shard_range', 'broadcast_module_state', 'broadcast_packed_state', 'packed_state_tensors', 'ShardedInference']
+__all__ = ['shard_range', 'broadcast_module_state', 'broadcast_packed_state', 'packed_state_tensors', 'replicas_agree', 'mark_local_state_authoritative', 'ShardedInference']
 
 import torch
 import torch.distributed as dist
@@ -55,8 +55,39 @@ def _broadcast_buckets(tensors, src, group, bucket_bytes):
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = _BUCKET_BYTES):
-    """Make every rank's parameters and buffers equal to rank `src`'s, with a few large broadcasts per dtype."""
-    return _broadcast_buckets([t for _, t in sorted(module.state_dict().items())], src, group, bucket_bytes)[0]
+    """Make every rank's parameters and buffers equal to rank `src`'s, with a few large broadcasts per dtype. Runners that held
+    packed state received from another rank (`broadcast_packed_state`) re-pack from the now-authoritative local tensors."""
+    n = _broadcast_buckets([t for _, t in sorted(module.state_dict().items())], src, group, bucket_bytes)[0]
+    for r in _runners(module):
+        r.local_state_restored()
+    return n
+
+
+def mark_local_state_authoritative(module: torch.nn.Module):
+    """After every rank has loaded the same fp32 state by itself (load_state_dict from the same file): forget that packed state
+    was once received from another rank, re-pack from the local tensors on next use."""
+    for r in _runners(module):
+        r.local_state_restored()
+
+
+def _runners_of(m):
+    from . import engine
+    for attr in sorted(vars(m)):
+        if not attr.startswith("_pcv"):
+            continue
+        v = vars(m)[attr]
+        items = [v] if not isinstance(v, (dict, list, tuple)) else (
+            [v[k] for k in sorted(v, key=repr)] if isinstance(v, dict) else list(v))
+        for r in items:
+            if isinstance(r, (engine.ConvRunner, engine.BnActRunner)):
+                yield r
+
+
+def _runners(module: torch.nn.Module):
+    """Every ConvRunner / BnActRunner hanging off `module`'s tree, in module order."""
+    for _, m in sorted(module.named_modules()):
+        for r in _runners_of(m):
+            yield r
 
 
 def packed_state_tensors(module: torch.nn.Module):
@@ -72,19 +103,8 @@ def packed_state_tensors(module: torch.nn.Module):
     tensors, hooks = [], []
     owned = set()
 
-    def runners_of(m):
-        for attr in sorted(vars(m)):
-            if not attr.startswith("_pcv"):
-                continue
-            v = vars(m)[attr]
-            items = [v] if not isinstance(v, (dict, list, tuple)) else (
-                [v[k] for k in sorted(v, key=repr)] if isinstance(v, dict) else list(v))
-            for r in items:
-                if isinstance(r, (engine.ConvRunner, engine.BnActRunner)):
-                    yield r
-
     for _, m in sorted(module.named_modules()):
-        for r in runners_of(m):
+        for r in _runners_of(m):
             if r.scale is None or r.shift is None:
                 raise RuntimeError("packed state requested before the first forward built every runner")
             if getattr(r, "packed", None) is not None:
@@ -104,14 +124,35 @@ def packed_state_tensors(module: torch.nn.Module):
 def broadcast_packed_state(module: torch.nn.Module, src: int = 0, group=None, bucket_bytes: int = _BUCKET_BYTES):
     """Serving-time weight distribution: rank `src`'s packed inference state (see `packed_state_tensors`) overwrites every
     other rank's. Half the bytes of the fp32 state for a 16-bit net, and the receiving ranks do not pack. After it, the fp32
-    parameters of convolutions on ranks != src are NOT those of `src` (only their packed form is): a later
-    `load_state_dict` / `set_compute_dtype` re-packs from whatever the module then holds, as on a single GPU.
+    parameters of convolutions on ranks != src are NOT those of `src` (only their packed form is), so the receiving runners are
+    marked (`ConvRunner.adopt_foreign_state`): running them in a configuration that needs a re-pack - another dtype, channel pitch
+    or padding parity, touched parameters - raises until `broadcast_module_state` (or a load_state_dict on every rank followed by
+    it) has made the fp32 state authoritative again.
     Returns (messages, bytes)."""
     tensors, hooks = packed_state_tensors(module)
     out = _broadcast_buckets(tensors, src, group, bucket_bytes)
     for h in hooks:
         h()
+    if (dist.get_rank(group) if dist.is_initialized() else 0) != src:
+        # the receivers' packed state no longer derives from their own fp32 parameters: a later key change (another input shape
+        # that flips a TF-"same" padding parity, another dtype or channel pitch) must not silently re-pack from them
+        for r in _runners(module):
+            r.adopt_foreign_state()
     return out
+
+
+def replicas_agree(values: torch.Tensor, group=None) -> bool:
+    """True when `values` (any small tensor: logits of a common input, a checksum) is identical on every rank: all-reduce MIN
+    and MAX of its float64 image and compare. What bench.py runs after the weight broadcast, so that a tensor the broadcast
+    missed shows up as an error instead of plausible logits on ranks != 0."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    v = values.detach().double().reshape(-1)
+    v = torch.nan_to_num(v, nan=1.0e300, posinf=1.0e301, neginf=-1.0e301)
+    lo, hi = v.clone(), v.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(torch.equal(lo, hi))
 
 
 class ShardedInference(object):
