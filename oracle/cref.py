@@ -18,9 +18,10 @@ def build():
 
 
 def lib():
+    """libcref.so, or the library named by ORACLE_CREF_LIB (the ASan + UBSan build, tests/test_host_sanitizers.py)."""
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libcref.so")
+        path = os.environ.get("ORACLE_CREF_LIB") or os.path.join(_HERE, "libcref.so")
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)

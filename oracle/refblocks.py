@@ -147,6 +147,10 @@ def f4_block_forward(name: str, sd: dict, x: torch.Tensor, quant: str | None = N
             return q.r(F.interpolate(x, size=(13, 10), mode="bilinear", align_corners=False))
         if name == "interp_nearest_up2":
             return q.r(F.interpolate(x, scale_factor=2, mode="nearest"))
+        if name == "interp_nearest_ignores_up_false":       # tutti.py:240-246: scale_factor goes straight to F.interpolate, `up` unread
+            return q.r(F.interpolate(x, scale_factor=2, mode="nearest"))
+        if name == "interp_nearest_ignores_out_size":       # ... and so is `out_size`
+            return q.r(F.interpolate(x, scale_factor=3, mode="nearest"))
         if name == "interp_bilinear_down2":
             return q.r(F.interpolate(x, size=(x.shape[2] // 2, x.shape[3] // 2), mode="bilinear", align_corners=True))
         if name == "concurrent_cat":

@@ -128,6 +128,17 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
     if (!dtype_ok(d.dtype) || !dtype_ok(d.out_dtype)) return "unknown dtype";
     if (d.out_dtype != d.dtype && d.out_dtype != PCV_F32) return "out_dtype must equal dtype or be fp32";
     if (d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.groups <= 0) return "non-positive conv dimension";
+    // ranges first: everything below is 32-bit arithmetic on these fields (UBSan-clean for any descriptor: tests/test_host_sanitizers.py)
+    constexpr int kMaxChannels = 1 << 20, kMaxExtent = 1 << 24, kMaxGeom = 1 << 12;
+    if (d.Cin > kMaxChannels || d.Cout > kMaxChannels || d.groups > kMaxChannels) return "channel count out of range (> 2^20)";
+    if (d.N < 0 || d.H < 0 || d.W < 0 || d.N > kMaxExtent || d.H > kMaxExtent || d.W > kMaxExtent) return "N / H / W out of range (> 2^24)";
+    if (d.stride_h > kMaxGeom || d.stride_w > kMaxGeom || d.dil_h > kMaxGeom || d.dil_w > kMaxGeom) return "stride / dilation out of range";
+    if (d.pad_t < 0 || d.pad_l < 0 || d.pad_b < 0 || d.pad_r < 0 || d.pad_t > kMaxGeom || d.pad_l > kMaxGeom || d.pad_b > kMaxGeom ||
+        d.pad_r > kMaxGeom)
+        return "padding out of range";
+    if (d.x_cpitch < 0 || d.x_cpitch > 8 * kMaxChannels || d.x_wpitch < 0 || d.x_wpitch > 2 * kMaxExtent || d.y_cpitch < 0 ||
+        d.y_cpitch > 8 * kMaxChannels)
+        return "pitch out of range";
     if (d.kh >= IGEMM_MAX_TAPS || d.kw >= IGEMM_MAX_TAPS) return "kernel size > 15 unsupported";
     if (d.stride_h <= 0 || d.stride_w <= 0 || d.dil_h <= 0 || d.dil_w <= 0) return "non-positive stride/dilation";
     if (d.Cin % d.groups || d.Cout % d.groups) return "channels not divisible by groups";
@@ -971,238 +982,42 @@ int pcv_bn_fold(pcv_ctx* ctx, int C, const float* gamma, const float* beta, cons
 static int pool_out(int in, int k, int s, int p, int ceil_mode);
 static void launch_se_fc(const float* in, const float* w, const float* b, float* out, int N, int K, int J, int act, hipStream_t st);
 
-// pool: the MaxPool2d(3, 2, 1) of the init block fused behind the stem convolution (pcv_conv2d_maxpool_fused)
-// x_nchw: the stem convolution reads the fp32 NCHW image itself (pcv_conv2d_nchw_stem_fused); `d` still describes the padded NHWC4 view
-static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
-                       const float* shift, const void* residual, void* y, void* stream, bool pool, const float* gate = nullptr,
-                       bool x_nchw = false) {
-    if (!ctx) return PCV_ERR_INVALID;
-    DeviceGuard device_guard(ctx->device);
-    if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
-    if (d->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: has_residual but residual is NULL");
-    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty input");
-    if (d->groups > 1 && d->groups == d->Cin && d->Cin == d->Cout)
-        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: depthwise convolution goes through pcv_dwconv2d_fused");
-    ConvPlan P;
-    const char* why = plan_conv(*d, P, false);
-    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv2d_fused: ") + why);
-    if (P.Ho <= 0 || P.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty output");
-    const int cpitch = d->x_cpitch > 0 ? d->x_cpitch : d->Cin;
-    const int wpitch = d->x_wpitch > 0 ? d->x_wpitch : d->W;
-    const unsigned long long xbytes = (unsigned long long)d->N * d->H * wpitch * cpitch * P.ES;
-    const unsigned long long M64 = (unsigned long long)d->N * P.Ho * P.Wo;
-    if (xbytes >= 0x80000000ull || M64 >= 0x7FFFFFFFull)
-        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: input exceeds the 2 GiB window of one launch; split the batch");
-    if (!aligned16(x) || !aligned16(packed) || !aligned16(y) || (residual && !aligned16(residual)) ||
-        (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
-        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
+// ---------------------------------------------------------------------------------------------------------
+// One convolution launch = route (which kernel family, which tile shape: a pure function of the descriptor, the plan and the
+// context's switches) + that family's launcher (parameter block, grid, launch). conv2d_impl validates, routes, dispatches.
+// ---------------------------------------------------------------------------------------------------------
+enum ConvKernel {
+    CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
+    CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
+    CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
+    CK_D3Q,         // d3q_conv.hpp: dense 3x3 / s1 / p1, 16 bit
+    CK_D3Q_1X1,     // d3q_conv.hpp in its 1x1 mode: K-heavy pointwise layers
+    CK_HEAD,        // head_gemm.hpp: fp32 dense layer on a 1x1 map (classifier)
+    CK_IGEMM        // igemm_conv.hpp: everything else
+};
+struct ConvRoute {
+    ConvKernel kernel = CK_IGEMM;
+    int shape = -1;             // CK_D3Q / CK_D3Q_1X1: index into kD3 / kD1
+    GConvRPlan rows{};          // CK_GCONV_ROWS
+    int tile = TILE_C128, khw = 0;      // CK_IGEMM: tile configuration, tap mode (0 table, 1 = 1x1, 9 = 3x3)
+    bool special = false;       // CK_IGEMM: ragged channel count or fp32 output (the descriptor-driven 128 x 128 variants)
+};
+// what a launch addresses besides the descriptor
+struct ConvArgs {
+    const void* x; const void* packed; const float* scale; const float* shift; const void* residual; void* y;
+    const float* gate; hipStream_t stream;
+    bool pool;                  // the MaxPool2d(3, 2, 1) of the init block fused behind the stem convolution (pcv_conv2d_maxpool_fused)
+    bool x_nchw;                // the stem reads the fp32 NCHW image itself (pcv_conv2d_nchw_stem_fused); `d` still describes the padded NHWC4 view
+};
+// sizes every launcher needs
+struct ConvGeom {
+    int cpitch, wpitch;
+    unsigned long long xbytes, M64;
+    bool sliced_y;
+};
 
-    const bool sliced_y = d->y_cpitch > 0 && d->y_cpitch != d->Cout;
-    if (P.stem && sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
-    if (gate && (P.stem || pool)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: the stem kernel has no gate");
-    if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
-    if (x_nchw && (!P.stem || d->Cin > 3 || d->W % 4 != 0))
-        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_nchw_stem_fused: only the stem convolution (<= 3 input planes, W a multiple of 4)");
-    if (x_nchw && (unsigned long long)d->N * d->Cin * d->H * d->W * 4ull >= 0x80000000ull)
-        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_nchw_stem_fused: the fp32 image batch exceeds the 2 GiB window of one launch; split the batch");
-    if (P.stem) {
-        StemParams q;
-        q.x = x; q.w = packed; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
-        q.x_bytes = x_nchw ? (uint32_t)((unsigned long long)d->N * d->Cin * d->H * d->W * 4ull) : (uint32_t)xbytes;
-        q.w_bytes = (uint32_t)P.w_bytes; q.Cin = d->Cin;
-        q.Hq = pool ? pool_out(P.Ho, 3, 2, 1, 0) : P.Ho;
-        q.Wq = pool ? pool_out(P.Wo, 3, 2, 1, 0) : P.Wo;
-        const unsigned long long ybytes = (unsigned long long)d->N * q.Hq * q.Wq * (unsigned long long)d->Cout * P.ES;
-        if (ybytes >= 0x80000000ull)
-            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
-        q.y_bytes = (uint32_t)ybytes;
-        q.N = d->N; q.H = d->H; q.W = d->W; q.Wp = wpitch; q.Ho = P.Ho; q.Wo = P.Wo; q.Cout = d->Cout;
-        q.kh = d->kh; q.pt = d->pad_t; q.x0off = -(d->pad_l + (d->pad_l & 1));
-        q.tilesH = pool ? (q.Hq + 6) / 7 : (P.Ho + 15) / 16;
-        q.tilesW = pool ? (q.Wq + 6) / 7 : (P.Wo + 15) / 16;
-        const long long nT = (long long)d->N * q.tilesH * q.tilesW;
-        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
-        q.nTiles = (int)nT;
-        q.act = d->act;
-        if (d->has_residual || d->post_act != PCV_ACT_NONE)
-            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel has no residual / post-activation path");
-        long long nb = block_slots(ctx, g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1]);
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        const bool bf = d->dtype == PCV_BF16;
-        const dim3 g((unsigned)nb), b(256);
-        hipStream_t st = (hipStream_t)stream;
-        if (x_nchw) {
-            const int lds = kStemLds + kStemStageBytes;
-            if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true, true>), g, b, lds, st, q);
-            else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true, true>), g, b, lds, st, q);
-            else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false, true>), g, b, lds, st, q);
-            else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false, true>), g, b, lds, st, q);
-        } else if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true>), g, b, kStemLds, st, q);
-        else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true>), g, b, kStemLds, st, q);
-        else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false>), g, b, kStemLds, st, q);
-        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false>), g, b, kStemLds, st, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-
-    const bool gconv_ok = P.gconv && !gate && !sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && cpitch == d->Cin &&
-                          wpitch == d->W && M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull;
-    // stride 2 (even maps) or 32 channels per group: whole output rows per tile (gconv3x3r.hpp)
-    GConvRPlan gr;
-    if (gconv_ok && ctx->use_gconvr != 0 && (d->stride_h == 2 || P.gconv_kt == 9) &&
-        plan_gconvr(d->stride_h, d->H, d->W, P.Ho, P.Wo, gr)) {
-        GConvRParams q;
-        std::memset(&q, 0, sizeof(q));
-        q.x = x; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
-        q.w = static_cast<const char*>(packed) + P.gconv_off;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
-        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
-        q.Min = d->N * d->H * d->W; q.Mout = (int)M64;
-        q.W = d->W; q.Wo = P.Wo; q.Ho = P.Ho; q.C = d->Cin;
-        q.R = gr.R; q.RWo = gr.R * P.Wo; q.XH = gr.XH; q.xl = gr.xl; q.win = gr.win;
-        q.div_wo = make_fastdiv((uint32_t)P.Wo);
-        q.div_ho = make_fastdiv((uint32_t)P.Ho);
-        const long long rows = (long long)d->N * P.Ho;
-        q.nRowTiles = (int)((rows + gr.R - 1) / gr.R);
-        const long long nT = (long long)q.nRowTiles * (d->Cin / 64);
-        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
-        q.nTiles = (int)nT;
-        q.act = d->act;
-        const int lds = 2 * gr.xl * 32 * 128;
-        long long nb = block_slots(ctx, lds * 2 <= 160 * 1024 ? 2 : 1);
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        hipLaunchKernelGGL(pick_gconvr(d->dtype, d->stride_h, P.gconv_kt), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-    if (gconv_ok && d->stride_h == 1 && P.gconv_kt == 5 && d->W <= 63) {
-        GConvParams q;
-        std::memset(&q, 0, sizeof(q));
-        q.x = x; q.y = y; q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
-        q.w = static_cast<const char*>(packed) + P.gconv_off;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
-        q.y_bytes = (uint32_t)(M64 * (unsigned long long)d->Cin * 2ull);
-        q.M = (int)M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.HW = d->H * d->W;
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
-        q.nPixTiles = (int)((M64 + 127) / 128);
-        const long long nT = (long long)q.nPixTiles * (d->Cin / 64);
-        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
-        q.nTiles = (int)nT;
-        q.act = d->act;
-        const GConvLaunch L = pick_gconv(d->dtype, d->W);
-        const int wi = d->W + 1 <= 16 ? 0 : (d->W + 1 <= 32 ? 1 : 2);
-        long long nb = block_slots(ctx, g_gconv_blocks_per_cu[wi]);
-        if (nb > nT) nb = nT;
-        nb = (nb + 7) / 8 * 8;
-        hipLaunchKernelGGL(L.fn, dim3((unsigned)nb), dim3(256), L.lds, (hipStream_t)stream, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-    // ---- dense 3x3 / s1 / p1, 16 bit: the 8-wave kernel -----------------------------------------------------------------------
-    int d3shape = -1;
-    if (P.conv3 && !gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && d->act <= PCV_ACT_RELU6 && d->post_act <= PCV_ACT_RELU6 &&
-        scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull &&
-        xbytes + 2ull * (unsigned long long)d->W * d->Cin * 2ull < 0x80000000ull) {
-        d3shape = ctx->use_d3x3 > 0 ? std::min(ctx->use_d3x3 - 1, kD3Count - 1)
-                                    : pick_d3x3((long long)M64, d->Cout, P.nk, (long long)ctx->num_cu);
-    }
-    if (d3shape >= 0) {
-        const int ypitch3 = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
-        const unsigned long long ybytes3 = ((M64 - 1) * (unsigned long long)ypitch3 + d->Cout) * 2ull;
-        if (ypitch3 < d->Cout || (ypitch3 * 2) % 16 != 0)
-            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
-        if (ybytes3 >= 0x80000000ull)
-            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
-        const long long slots = block_slots(ctx, 1);
-        const D3Shape& S = kD3[d3shape];
-        D3Params q;
-        std::memset(&q, 0, sizeof(q));
-        q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
-        q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes3;
-        q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
-        q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch3;
-        q.H = d->H; q.W = d->W; q.Cin = d->Cin; q.HW = d->H * d->W;
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)d->W);
-        q.stride = 1; q.Hin = d->H; q.Win = d->W;
-        q.nk = P.nk; q.slices = d->Cin / 64; q.Kpad = P.Kpad;
-        q.act = d->act; q.post_act = d->post_act;
-        q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
-        const long long nT = ((long long)((M64 + S.BP - 1) / S.BP)) * q.nChTiles;
-        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
-        q.nTiles = (int)nT;
-        q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
-        long long nb = slots < nT ? slots : nT;
-        nb = (nb + 7) / 8 * 8;
-        void* args[] = {&q};
-        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));
-        return PCV_OK;
-    }
-
-    // ---- K-heavy 1x1 / stride 1, 16 bit: d3q_kernel's 1x1 mode ---------------------------------------------------------------------
-    int d1shape = -1;
-    if (ctx->use_d1x1 != 0 && !gate && !P.pair && d->dtype != PCV_F32 && d->out_dtype == d->dtype && d->kh == 1 && d->kw == 1 &&
-        d->stride_h == d->stride_w && d->stride_h <= 2 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
-        cpitch == d->Cin && wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && d->act <= PCV_ACT_RELU6 &&
-        d->post_act <= PCV_ACT_RELU6 && scale && shift && M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
-        d1shape = ctx->use_d1x1 > 0 ? std::min(ctx->use_d1x1 - 1, kD1Count - 1)
-                                    : pick_d1x1((long long)M64, d->Cout, d->Cin, (long long)block_slots(ctx, 1));
-    }
-    if (d1shape >= 0) {
-        const int ypitch1 = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
-        const unsigned long long ybytes1 = ((M64 - 1) * (unsigned long long)ypitch1 + d->Cout) * 2ull;
-        if (ypitch1 < d->Cout || (ypitch1 * 2) % 16 != 0)
-            return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
-        if (ybytes1 >= 0x80000000ull)
-            return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
-        const D3Shape& S = kD1[d1shape];
-        D3Params q;
-        std::memset(&q, 0, sizeof(q));
-        q.x = x; q.w = static_cast<const char*>(packed) + P.ktab_bytes; q.res = d->has_residual ? residual : nullptr; q.y = y;
-        q.scale = scale; q.shift = shift; q.ovf = ctx->ovf;
-        q.x_bytes = (uint32_t)xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes1;
-        q.res_bytes = (uint32_t)(M64 * (unsigned long long)d->Cout * 2ull);
-        q.M = (int)M64; q.Cout = d->Cout; q.Ypitch = ypitch1;
-        q.H = P.Ho; q.W = P.Wo; q.Cin = d->Cin; q.HW = P.Ho * P.Wo;                 // the OUTPUT map (a strided 1x1 reads every stride-th pixel)
-        q.div_hw = make_fastdiv((uint32_t)q.HW);
-        q.div_w = make_fastdiv((uint32_t)P.Wo);
-        q.stride = d->stride_h; q.Hin = d->H; q.Win = d->W;
-        q.nk = d->Cin / 64; q.slices = q.nk; q.Kpad = P.Kpad;
-        q.act = d->act; q.post_act = d->post_act;
-        q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
-        const long long nT = ((long long)((M64 + S.BP - 1) / S.BP)) * q.nChTiles;
-        if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
-        q.nTiles = (int)nT;
-        const long long slots1 = block_slots(ctx, 1);
-        long long nb = slots1 < nT ? slots1 : nT;
-        nb = (nb + 7) / 8 * 8;
-        void* args[] = {&q};
-        HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, (hipStream_t)stream));
-        return PCV_OK;
-    }
-
-    // ---- dense layer on a 1x1 map, fp32 (classifier): many small blocks instead of a handful of 128x128 tiles ------------------
-    if (ctx->use_head && d->dtype == PCV_F32 && d->out_dtype == PCV_F32 && d->kh == 1 && d->kw == 1 && d->H == 1 && d->W == 1 &&
-        P.Ho == 1 && P.Wo == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 && !gate &&
-        !d->has_residual && d->post_act == PCV_ACT_NONE && d->Cin % 16 == 0) {
-        const int ypitchh = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
-        if (ypitchh < d->Cout) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout");
-        HeadParams q;
-        q.x = static_cast<const float*>(x); q.w = reinterpret_cast<const float*>(static_cast<const char*>(packed) + P.ktab_bytes);
-        q.scale = scale; q.shift = shift; q.y = static_cast<float*>(y);
-        q.M = d->N; q.K = d->Cin; q.Kpad = P.Kpad; q.Cout = d->Cout; q.Xpitch = cpitch; q.Ypitch = ypitchh; q.act = d->act;
-        const unsigned gx = (unsigned)(P.wrows / 32);
-        const bool wide = (long long)gx * ((d->N + 31) / 32) >= 2ll * ctx->num_cu;      // enough 32-image blocks for two per CU
-        if (wide) hipLaunchKernelGGL(head_gemm_f32_kernel<32>, dim3(gx, (unsigned)((d->N + 31) / 32)), dim3(256), 0, (hipStream_t)stream, q);
-        else hipLaunchKernelGGL(head_gemm_f32_kernel<16>, dim3(gx, (unsigned)((d->N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, q);
-        HIP_TRY(ctx, hipGetLastError());
-        return PCV_OK;
-    }
-
+// Tile configuration of the generic kernel for a plan (tests/tools/sweep_1x1_tiles.py has the measurements behind the rules).
+static void route_igemm(const pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, ConvRoute& R) {
     const bool ragged = (d->Cout % 8 != 0) || (P.cout_blk % 8 != 0);
     int tile;
     if (ragged || d->out_dtype != d->dtype) tile = TILE_C128;
@@ -1211,16 +1026,15 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     else if (P.cout_blk <= 128) tile = TILE_C128;
     else if (P.cout_blk <= 256) tile = (d->kh * d->kw > 1) ? TILE_C128 : TILE_C256;   // 256x64 only pays for HBM-bound 1x1 (reads x once)
     else tile = TILE_C128;
-    if (ragged && P.ngb != 1) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
-    const bool special = ragged || d->out_dtype != d->dtype;
+    R.special = ragged || d->out_dtype != d->dtype;
     int khw = 0;
-    if (!special && !P.pair && d->dil_h == 1 && d->dil_w == 1) {
+    if (!R.special && !P.pair && d->dil_h == 1 && d->dil_w == 1) {
         if (d->kh == 1 && d->kw == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0) khw = 1;
         else if (d->kh == 3 && d->kw == 3 && P.cin_blk % (8 * P.CE) == 0) khw = 9;
     }
     if (khw == 1) {
         // 1x1 reductions (many K-steps into few channels) run best on the half-height tiles (3 blocks per CU); the 256-channel
-        // tile only pays when the input is narrow (it reads x once) - tests/tools/sweep_1x1_tiles.py
+        // tile only pays when the input is narrow (it reads x once)
         if (tile == TILE_C64 && d->Cin >= 256) tile = TILE_C64S;
         else if (tile == TILE_C128 && P.cout_blk <= 128 && d->Cin >= 512) tile = TILE_C128S;
         else if (tile == TILE_C256 && d->Cin > 128) tile = TILE_C128;
@@ -1233,34 +1047,229 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
             tile = pad64 < pad128 ? TILE_C64S : TILE_C128S;
         }
     }
-    if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !special && (ctx->force_tile < TILE_C64S || khw == 1))
+    if (ctx->force_tile >= 0 && ctx->force_tile < TILE_COUNT && !R.special && (ctx->force_tile < TILE_C64S || khw == 1))
         tile = ctx->force_tile;
-    igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, special, tile, khw);
+    R.tile = tile;
+    R.khw = khw;
+}
+
+static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
+    ConvRoute R;
+    if (P.stem) { R.kernel = CK_STEM; return R; }
+    const bool gconv_ok = P.gconv && !A.gate && !G.sliced_y && !d->has_residual && d->post_act == PCV_ACT_NONE && G.cpitch == d->Cin &&
+                          G.wpitch == d->W && G.M64 * (unsigned long long)d->Cin * 2ull < 0x80000000ull;
+    // stride 2 (even maps) or 32 channels per group: whole output rows per tile
+    if (gconv_ok && ctx->use_gconvr != 0 && (d->stride_h == 2 || P.gconv_kt == 9) &&
+        plan_gconvr(d->stride_h, d->H, d->W, P.Ho, P.Wo, R.rows)) { R.kernel = CK_GCONV_ROWS; return R; }
+    if (gconv_ok && d->stride_h == 1 && P.gconv_kt == 5 && d->W <= 63) { R.kernel = CK_GCONV_FLAT; return R; }
+    const bool clamp_acts = d->act <= PCV_ACT_RELU6 && d->post_act <= PCV_ACT_RELU6;       // the 8-wave kernel's branch-free epilogue
+    if (P.conv3 && !A.gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && clamp_acts && A.scale && A.shift &&
+        G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull &&
+        G.xbytes + 2ull * (unsigned long long)d->W * d->Cin * 2ull < 0x80000000ull) {
+        R.shape = ctx->use_d3x3 > 0 ? std::min(ctx->use_d3x3 - 1, kD3Count - 1)
+                                    : pick_d3x3((long long)G.M64, d->Cout, P.nk, (long long)ctx->num_cu);
+        if (R.shape >= 0) { R.kernel = CK_D3Q; return R; }
+    }
+    if (ctx->use_d1x1 != 0 && !A.gate && !P.pair && d->dtype != PCV_F32 && d->out_dtype == d->dtype && d->kh == 1 && d->kw == 1 &&
+        d->stride_h == d->stride_w && d->stride_h <= 2 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
+        G.cpitch == d->Cin && G.wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && clamp_acts && A.scale && A.shift &&
+        G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        R.shape = ctx->use_d1x1 > 0 ? std::min(ctx->use_d1x1 - 1, kD1Count - 1)
+                                    : pick_d1x1((long long)G.M64, d->Cout, d->Cin, (long long)block_slots(ctx, 1));
+        if (R.shape >= 0) { R.kernel = CK_D3Q_1X1; return R; }
+    }
+    if (ctx->use_head && d->dtype == PCV_F32 && d->out_dtype == PCV_F32 && d->kh == 1 && d->kw == 1 && d->H == 1 && d->W == 1 &&
+        P.Ho == 1 && P.Wo == 1 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 && !A.gate &&
+        !d->has_residual && d->post_act == PCV_ACT_NONE && d->Cin % 16 == 0) { R.kernel = CK_HEAD; return R; }
+    route_igemm(ctx, d, P, R);
+    return R;
+}
+
+static int launch_stem(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
+    const bool pool = A.pool, x_nchw = A.x_nchw;
+    StemParams q;
+    q.x = A.x; q.w = A.packed; q.y = A.y; q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.x_bytes = x_nchw ? (uint32_t)((unsigned long long)d->N * d->Cin * d->H * d->W * 4ull) : (uint32_t)G.xbytes;
+    q.w_bytes = (uint32_t)P.w_bytes; q.Cin = d->Cin;
+    q.Hq = pool ? pool_out(P.Ho, 3, 2, 1, 0) : P.Ho;
+    q.Wq = pool ? pool_out(P.Wo, 3, 2, 1, 0) : P.Wo;
+    const unsigned long long ybytes = (unsigned long long)d->N * q.Hq * q.Wq * (unsigned long long)d->Cout * P.ES;
+    if (ybytes >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+    q.y_bytes = (uint32_t)ybytes;
+    q.N = d->N; q.H = d->H; q.W = d->W; q.Wp = G.wpitch; q.Ho = P.Ho; q.Wo = P.Wo; q.Cout = d->Cout;
+    q.kh = d->kh; q.pt = d->pad_t; q.x0off = -(d->pad_l + (d->pad_l & 1));
+    q.tilesH = pool ? (q.Hq + 6) / 7 : (P.Ho + 15) / 16;
+    q.tilesW = pool ? (q.Wq + 6) / 7 : (P.Wo + 15) / 16;
+    const long long nT = (long long)d->N * q.tilesH * q.tilesW;
+    if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    q.nTiles = (int)nT;
+    q.act = d->act;
+    if (d->has_residual || d->post_act != PCV_ACT_NONE)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel has no residual / post-activation path");
+    long long nb = block_slots(ctx, g_stem_blocks_per_cu[d->dtype == PCV_BF16 ? 0 : 1]);
+    if (nb > nT) nb = nT;
+    nb = (nb + 7) / 8 * 8;
+    const bool bf = d->dtype == PCV_BF16;
+    const dim3 g((unsigned)nb), b(256);
+    hipStream_t st = A.stream;
+    if (x_nchw) {
+        const int lds = kStemLds + kStemStageBytes;
+        if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true, true>), g, b, lds, st, q);
+        else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true, true>), g, b, lds, st, q);
+        else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false, true>), g, b, lds, st, q);
+        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false, true>), g, b, lds, st, q);
+    } else if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true>), g, b, kStemLds, st, q);
+    else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true>), g, b, kStemLds, st, q);
+    else if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false>), g, b, kStemLds, st, q);
+    else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false>), g, b, kStemLds, st, q);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+static int launch_gconv_rows(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A,
+                             const GConvRPlan& gr) {
+    GConvRParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = A.x; q.y = A.y; q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.w = static_cast<const char*>(A.packed) + P.gconv_off;
+    q.x_bytes = (uint32_t)G.xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
+    q.y_bytes = (uint32_t)(G.M64 * (unsigned long long)d->Cin * 2ull);
+    q.Min = d->N * d->H * d->W; q.Mout = (int)G.M64;
+    q.W = d->W; q.Wo = P.Wo; q.Ho = P.Ho; q.C = d->Cin;
+    q.R = gr.R; q.RWo = gr.R * P.Wo; q.XH = gr.XH; q.xl = gr.xl; q.win = gr.win;
+    q.div_wo = make_fastdiv((uint32_t)P.Wo);
+    q.div_ho = make_fastdiv((uint32_t)P.Ho);
+    const long long rows = (long long)d->N * P.Ho;
+    q.nRowTiles = (int)((rows + gr.R - 1) / gr.R);
+    const long long nT = (long long)q.nRowTiles * (d->Cin / 64);
+    if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    q.nTiles = (int)nT;
+    q.act = d->act;
+    const int lds = 2 * gr.xl * 32 * 128;
+    long long nb = block_slots(ctx, lds * 2 <= 160 * 1024 ? 2 : 1);
+    if (nb > nT) nb = nT;
+    nb = (nb + 7) / 8 * 8;
+    hipLaunchKernelGGL(pick_gconvr(d->dtype, d->stride_h, P.gconv_kt), dim3((unsigned)nb), dim3(256), lds, A.stream, q);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+static int launch_gconv_flat(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
+    GConvParams q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = A.x; q.y = A.y; q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.w = static_cast<const char*>(A.packed) + P.gconv_off;
+    q.x_bytes = (uint32_t)G.xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.gconv_off);
+    q.y_bytes = (uint32_t)(G.M64 * (unsigned long long)d->Cin * 2ull);
+    q.M = (int)G.M64; q.H = d->H; q.W = d->W; q.C = d->Cin; q.HW = d->H * d->W;
+    q.div_hw = make_fastdiv((uint32_t)q.HW);
+    q.div_w = make_fastdiv((uint32_t)d->W);
+    q.nPixTiles = (int)((G.M64 + 127) / 128);
+    const long long nT = (long long)q.nPixTiles * (d->Cin / 64);
+    if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    q.nTiles = (int)nT;
+    q.act = d->act;
+    const GConvLaunch L = pick_gconv(d->dtype, d->W);
+    const int wi = d->W + 1 <= 16 ? 0 : (d->W + 1 <= 32 ? 1 : 2);
+    long long nb = block_slots(ctx, g_gconv_blocks_per_cu[wi]);
+    if (nb > nT) nb = nT;
+    nb = (nb + 7) / 8 * 8;
+    hipLaunchKernelGGL(L.fn, dim3((unsigned)nb), dim3(256), L.lds, A.stream, q);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+// d3q_kernel, both modes: `one` = the 1x1 mode (kD1 shapes; H / W / HW describe the OUTPUT map, a strided 1x1 reads every
+// stride-th pixel), else the dense 3x3 mode (kD3 shapes)
+static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, int shape, bool one) {
+    const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+    const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * 2ull;
+    if (ypitch < d->Cout || (ypitch * 2) % 16 != 0)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
+    if (ybytes >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+    const D3Shape& S = one ? kD1[shape] : kD3[shape];
+    D3Params q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
+    q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.x_bytes = (uint32_t)G.xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes;
+    q.res_bytes = (uint32_t)(G.M64 * (unsigned long long)d->Cout * 2ull);
+    q.M = (int)G.M64; q.Cout = d->Cout; q.Ypitch = ypitch; q.Cin = d->Cin; q.Kpad = P.Kpad;
+    q.Hin = d->H; q.Win = d->W;
+    if (one) {
+        q.H = P.Ho; q.W = P.Wo; q.HW = P.Ho * P.Wo;
+        q.div_w = make_fastdiv((uint32_t)P.Wo);
+        q.stride = d->stride_h;
+        q.nk = d->Cin / 64; q.slices = q.nk;
+    } else {
+        q.H = d->H; q.W = d->W; q.HW = d->H * d->W;
+        q.div_w = make_fastdiv((uint32_t)d->W);
+        q.stride = 1;
+        q.nk = P.nk; q.slices = d->Cin / 64;
+        q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
+    }
+    q.div_hw = make_fastdiv((uint32_t)q.HW);
+    q.act = d->act; q.post_act = d->post_act;
+    q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
+    const long long nT = ((long long)((G.M64 + S.BP - 1) / S.BP)) * q.nChTiles;
+    if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    q.nTiles = (int)nT;
+    const long long slots = block_slots(ctx, 1);
+    long long nb = slots < nT ? slots : nT;
+    nb = (nb + 7) / 8 * 8;
+    void* args[] = {&q};
+    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, A.stream));
+    return PCV_OK;
+}
+
+// dense layer on a 1x1 map, fp32 (classifier): many small blocks instead of a handful of 128x128 tiles
+static int launch_head(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
+    const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+    if (ypitch < d->Cout) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout");
+    HeadParams q;
+    q.x = static_cast<const float*>(A.x); q.w = reinterpret_cast<const float*>(static_cast<const char*>(A.packed) + P.ktab_bytes);
+    q.scale = A.scale; q.shift = A.shift; q.y = static_cast<float*>(A.y);
+    q.M = d->N; q.K = d->Cin; q.Kpad = P.Kpad; q.Cout = d->Cout; q.Xpitch = G.cpitch; q.Ypitch = ypitch; q.act = d->act;
+    const unsigned gx = (unsigned)(P.wrows / 32);
+    const bool wide = (long long)gx * ((d->N + 31) / 32) >= 2ll * ctx->num_cu;      // enough 32-image blocks for two per CU
+    if (wide) hipLaunchKernelGGL(head_gemm_f32_kernel<32>, dim3(gx, (unsigned)((d->N + 31) / 32)), dim3(256), 0, A.stream, q);
+    else hipLaunchKernelGGL(head_gemm_f32_kernel<16>, dim3(gx, (unsigned)((d->N + 15) / 16)), dim3(256), 0, A.stream, q);
+    HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+static int launch_igemm(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, const ConvRoute& R) {
+    if (R.special && P.ngb != 1 && ((d->Cout % 8 != 0) || (P.cout_blk % 8 != 0)))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: ragged channel count with groups unsupported");
+    const int tile = R.tile, khw = R.khw;
+    igemm_fn fn = pick_igemm(d->dtype, d->out_dtype, R.special, tile, khw);
     if (!fn) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: no kernel for this dtype combination");
     const TileInfo& T = kTiles[tile];
 
     IgemmParams p;
-    p.x = x;
-    p.ktab = reinterpret_cast<const uint32_t*>(packed);
-    p.w = static_cast<const char*>(packed) + P.ktab_bytes;
-    p.res = d->has_residual ? residual : nullptr;
-    p.gate = gate;
+    p.x = A.x;
+    p.ktab = reinterpret_cast<const uint32_t*>(A.packed);
+    p.w = static_cast<const char*>(A.packed) + P.ktab_bytes;
+    p.res = d->has_residual ? A.residual : nullptr;
+    p.gate = A.gate;
     p.ovf = ctx->ovf;
-    p.y = y;
-    p.scale = scale;
-    p.shift = shift;
-    p.x_bytes = (uint32_t)xbytes;
+    p.y = A.y;
+    p.scale = A.scale;
+    p.shift = A.shift;
+    p.x_bytes = (uint32_t)G.xbytes;
     p.w_bytes = (uint32_t)P.w_bytes;
     const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
     if (ypitch < d->Cout || (ypitch != d->Cout && (ypitch * esize(d->out_dtype)) % 16 != 0))
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
     {
-        const unsigned long long ybytes = ((M64 - 1) * (unsigned long long)ypitch + d->Cout) * esize(d->out_dtype);
+        const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * esize(d->out_dtype);
         if (ybytes >= 0x80000000ull && d->out_dtype != PCV_F32)
             return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
         p.y_bytes = ybytes >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ybytes;
     }
-    p.M = (int)M64;
+    p.M = (int)G.M64;
     p.Cout = P.cout_blk;
     p.Cout_total = d->Cout;
     p.Ypitch = ypitch;
@@ -1273,8 +1282,8 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     p.div_wo = make_fastdiv((uint32_t)p.Wo);
     p.H = d->H;
     p.W = d->W;
-    p.Wpitch = wpitch;
-    p.Cpitch = cpitch;
+    p.Wpitch = G.wpitch;
+    p.Cpitch = G.cpitch;
     p.sh = d->stride_h;
     p.sw = d->stride_w;
     p.pt = d->pad_t;
@@ -1296,7 +1305,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     if (nTiles >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
     p.nTiles = (int)nTiles;
     // persistent grid: what is resident at once, a multiple of 8 so that every XCD gets the same number of blocks
-    const int bpc = special ? g_blocks_per_cu[d->dtype][1][tile][0] : g_blocks_per_cu[d->dtype][0][tile][khw_slot(khw)];
+    const int bpc = R.special ? g_blocks_per_cu[d->dtype][1][tile][0] : g_blocks_per_cu[d->dtype][0][tile][khw_slot(khw)];
     // Short K loops (HBM-bound 1x1 layers) run persistent, so that the next tile's loads overlap this tile's
     // epilogue; long K loops run one tile per block (the dispatcher refills a CU while the finished block's stores drain).
     const bool persistent = ctx->persist_mode == 1 || (ctx->persist_mode < 0 && P.nk <= ctx->persist_max_nk);
@@ -1305,9 +1314,55 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
     nblocks = (nblocks + 7) / 8 * 8;
     dim3 grid((unsigned)nblocks);
     p.wstat = (ctx->use_wstat && persistent && P.nk == 1 && p.nChTiles == 1 && P.ngb == 1) ? 1 : 0;
-    hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(fn, grid, dim3(T.threads), T.lds, A.stream, p);
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
+}
+
+static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,
+                       const float* shift, const void* residual, void* y, void* stream, bool pool, const float* gate = nullptr,
+                       bool x_nchw = false) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!d || !x || !packed || !y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: NULL argument");
+    if (d->has_residual && !residual) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: has_residual but residual is NULL");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty input");
+    if (d->groups > 1 && d->groups == d->Cin && d->Cin == d->Cout)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: depthwise convolution goes through pcv_dwconv2d_fused");
+    ConvPlan P;
+    const char* why = plan_conv(*d, P, false);
+    if (why) return fail(ctx, PCV_ERR_INVALID, std::string("pcv_conv2d_fused: ") + why);
+    if (P.Ho <= 0 || P.Wo <= 0) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: empty output");
+    ConvGeom G;
+    G.cpitch = d->x_cpitch > 0 ? d->x_cpitch : d->Cin;
+    G.wpitch = d->x_wpitch > 0 ? d->x_wpitch : d->W;
+    G.xbytes = (unsigned long long)d->N * d->H * G.wpitch * G.cpitch * P.ES;
+    G.M64 = (unsigned long long)d->N * P.Ho * P.Wo;
+    G.sliced_y = d->y_cpitch > 0 && d->y_cpitch != d->Cout;
+    if (G.xbytes >= 0x80000000ull || G.M64 >= 0x7FFFFFFFull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: input exceeds the 2 GiB window of one launch; split the batch");
+    if (!aligned16(x) || !aligned16(packed) || !aligned16(y) || (residual && !aligned16(residual)) ||
+        (scale && !aligned16(scale)) || (shift && !aligned16(shift)))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: pointers must be 16-byte aligned");
+    if (P.stem && G.sliced_y) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: the stem kernel writes a dense y only");
+    if (gate && (P.stem || pool)) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_gated_fused: the stem kernel has no gate");
+    if (pool && !P.stem) return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_maxpool_fused: only the stem convolution has a fused max-pool");
+    if (x_nchw && (!P.stem || d->Cin > 3 || d->W % 4 != 0))
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_nchw_stem_fused: only the stem convolution (<= 3 input planes, W a multiple of 4)");
+    if (x_nchw && (unsigned long long)d->N * d->Cin * d->H * d->W * 4ull >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_nchw_stem_fused: the fp32 image batch exceeds the 2 GiB window of one launch; split the batch");
+
+    const ConvArgs A{x, packed, scale, shift, residual, y, gate, (hipStream_t)stream, pool, x_nchw};
+    const ConvRoute R = route_conv(ctx, d, P, G, A);
+    switch (R.kernel) {
+        case CK_STEM: return launch_stem(ctx, d, P, G, A);
+        case CK_GCONV_ROWS: return launch_gconv_rows(ctx, d, P, G, A, R.rows);
+        case CK_GCONV_FLAT: return launch_gconv_flat(ctx, d, P, G, A);
+        case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
+        case CK_D3Q_1X1: return launch_d3q(ctx, d, P, G, A, R.shape, true);
+        case CK_HEAD: return launch_head(ctx, d, P, G, A);
+        default: return launch_igemm(ctx, d, P, G, A, R);
+    }
 }
 
 int pcv_conv2d_fused(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, const void* packed, const float* scale,

@@ -46,7 +46,7 @@ class ClassifierNet(nn.Module):
         self.features = nn.Sequential()
 
     def finish(self, width, head=None, init=init_conv_params):
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
+        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1, fp32_out=True))
         self.output = head if head is not None else LinearHead(in_features=width, out_features=self.num_classes)
         if init is not None:
             init(self)

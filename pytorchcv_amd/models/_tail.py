@@ -22,27 +22,28 @@ class MaxPool2dNHWC(nn.Module):
 
 
 class AvgPool2dNHWC(nn.Module):
-    """nn.AvgPool2d(kernel_size, stride) `final_pool` (reference resnet.py:316-318) -> pcv_avgpool2d. As a net's `final_pool`
-    (the classifier input) it hands fp32 pooled features to the fp32 head (engine.FP32_HEAD)."""
-    def __init__(self, kernel_size, stride):
+    """nn.AvgPool2d(kernel_size, stride) (reference resnet.py:316-318, densenet.py:60) -> pcv_avgpool2d. `fp32_out`: set by the nets
+    for their `final_pool` only - the classifier input - which hands fp32 pooled features to the fp32 head (engine.FP32_HEAD);
+    anywhere else (DenseNet's transition pools) the map stays in the storage type whatever its size."""
+    def __init__(self, kernel_size, stride, fp32_out=False):
         super(AvgPool2dNHWC, self).__init__()
-        self.kernel_size, self.stride = kernel_size, stride
+        self.kernel_size, self.stride, self.fp32_out = kernel_size, stride, bool(fp32_out)
 
     def forward(self, x):
-        head = engine.FP32_HEAD and isinstance(x, engine.NHWC) and x.H == self.kernel_size and x.W == self.kernel_size
+        head = engine.FP32_HEAD and self.fp32_out and isinstance(x, engine.NHWC)
         return engine.boundary(self, x, lambda a: engine.avgpool2d(a, self.kernel_size, self.stride, out_fp32=head))
 
 
 class GlobalAvgPool2dNHWC(nn.Module):
-    """nn.AdaptiveAvgPool2d(output_size=1) `final_pool` (reference efficientnet.py:339) -> pcv_global_avgpool."""
-    def __init__(self, output_size=1):
+    """nn.AdaptiveAvgPool2d(output_size=1) (reference efficientnet.py:339) -> pcv_global_avgpool; `fp32_out` as in AvgPool2dNHWC."""
+    def __init__(self, output_size=1, fp32_out=False):
         super(GlobalAvgPool2dNHWC, self).__init__()
         if output_size != 1:
             raise NotImplementedError("only AdaptiveAvgPool2d(1) is on the MI355X path")
-        self.output_size = output_size
+        self.output_size, self.fp32_out = output_size, bool(fp32_out)
 
     def forward(self, x):
-        head = engine.FP32_HEAD and isinstance(x, engine.NHWC)
+        head = engine.FP32_HEAD and self.fp32_out and isinstance(x, engine.NHWC)
         return engine.boundary(self, x, lambda a: engine.global_avgpool(a, out_fp32=head))
 
 

@@ -25,7 +25,8 @@ def _tail_conv(branch):
         mods = list(branch.children())
         head, tail = mods[:-1], mods[-1]
     if isinstance(tail, ConvBlock) and tail.conv.out_channels % 8 == 0 and not (
-            tail.conv.groups > 1 and tail.conv.groups == tail.conv.in_channels == tail.conv.out_channels):
+            tail.conv.groups > 1 and tail.conv.groups == tail.conv.in_channels == tail.conv.out_channels) and not (
+            tail.conv.in_channels <= 4 and max(tail.conv.stride) == 2):       # a stem-shaped convolution: its kernel writes a dense y only
         return head, tail
     return None
 
@@ -84,7 +85,8 @@ class Concurrent(nn.Sequential):
             return acc
         if self.axis != 1:
             raise NotImplementedError("Concurrent: concatenation along axis {} is not on the MI355X path".format(self.axis))
-        key = (a.N, a.H, a.W, a.C, a.dtype)
+        # the learnt branch shapes belong to THESE children: a child added or replaced later starts over
+        key = (a.N, a.H, a.W, a.C, a.dtype, tuple(id(m) for m in branches))
         shapes = self._pcv_shapes.get(key)
         if shapes is None:                                                  # first forward of this shape: learn the branch outputs
             outs = [m(a) for m in branches]
@@ -92,6 +94,7 @@ class Concurrent(nn.Sequential):
             if all(o.C % 8 == 0 for o in outs):
                 self._pcv_shapes[key] = [(o.H, o.W, o.C) for o in outs]
             return y
+        assert len(shapes) == len(branches)
         H, W = shapes[0][0], shapes[0][1]
         total = sum(c for _, _, c in shapes)
         buf = torch.empty((a.N, H, W, total), dtype=a.dtype, device=a.device)

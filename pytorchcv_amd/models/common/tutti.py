@@ -52,10 +52,25 @@ class InterpolationBlock(nn.Module):
         return (h // self.scale_factor, w // self.scale_factor)
 
     def forward(self, x, size=None):
+        """Reference tutti.py:225-238: bilinear (or an explicit `size`) interpolates to calc_out_size(x) / `size`; any other mode
+        without `size` calls F.interpolate(scale_factor=...), which ignores `out_size` and `up` - the output is the input size times
+        `scale_factor` - and, like torch, refuses an `align_corners` that is not None."""
         if self.mode not in ("bilinear", "nearest"):
             raise NotImplementedError("InterpolationBlock mode {} is not on the MI355X path".format(self.mode))
-        out_size = tuple(size) if size is not None else self.calc_out_size(x)
         bilinear = self.mode == "bilinear"
+        if not bilinear and self.align_corners is not None:
+            raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | trilinear")
+        if bilinear or size is not None:
+            out_size = tuple(size) if size is not None else self.calc_out_size(x)
+        else:
+            h, w = (x.H, x.W) if isinstance(x, engine.NHWC) else tuple(x.shape[2:])
+            oh, ow = h * self.scale_factor, w * self.scale_factor
+            if oh != int(oh) or ow != int(ow) or oh < 1 or ow < 1:
+                # (F.interpolate would floor the size but keep 1 / scale_factor as the source step: not the size-derived step of
+                # pcv_interpolate)
+                raise NotImplementedError("nearest interpolation by scale_factor {} of a {}x{} map: only whole output sizes are on the "
+                                          "MI355X path".format(self.scale_factor, h, w))
+            out_size = (int(oh), int(ow))
         return engine.boundary(self, x, lambda a: engine.interpolate(a, out_size, bilinear, bool(self.align_corners) if bilinear else False))
 
     def __repr__(self):

@@ -107,7 +107,7 @@ class DenseNet(nn.Module):
                 in_channels = out_channels
             self.features.add_module("stage{}".format(i + 1), stage)
         self.features.add_module("post_activ", PreResActivation(in_channels=in_channels))
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
+        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1, fp32_out=True))
         self.output = LinearHead(in_features=in_channels, out_features=num_classes)
         init_conv_params(self)
 

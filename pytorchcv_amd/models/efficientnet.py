@@ -136,7 +136,7 @@ class EfficientNet(nn.Module):
         self.features.add_module("final_block", conv1x1_block(in_channels=in_channels, out_channels=final_block_channels,
                                                               normalization=normalization, activation=activation))
         in_channels = final_block_channels
-        self.features.add_module("final_pool", GlobalAvgPool2dNHWC(output_size=1))
+        self.features.add_module("final_pool", GlobalAvgPool2dNHWC(output_size=1, fp32_out=True))
         self.output = nn.Sequential()
         if dropout_rate > 0.0:
             self.output.add_module("dropout", nn.Dropout(p=dropout_rate))      # identity at inference: never launched

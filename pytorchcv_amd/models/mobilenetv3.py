@@ -111,7 +111,7 @@ class MobileNetV3(nn.Module):
         self.features.add_module("final_block", MobileNetV3FinalBlock(in_channels=in_channels, out_channels=final_block_channels,
                                                                       use_se=final_use_se))
         in_channels = final_block_channels
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
+        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1, fp32_out=True))
         self.output = MobileNetV3Classifier(in_channels=in_channels, out_channels=num_classes,
                                             mid_channels=classifier_mid_channels, dropout_rate=0.2)
         init_conv_params(self)

@@ -140,7 +140,7 @@ class ResNet(nn.Module):
                                                                  conv1_stride=conv1_stride))
                 in_channels = out_channels
             self.features.add_module("stage{}".format(i + 1), stage)
-        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1))
+        self.features.add_module("final_pool", AvgPool2dNHWC(kernel_size=7, stride=1, fp32_out=True))
         self.output = LinearHead(in_features=in_channels, out_features=num_classes)
         init_conv_params(self)
 

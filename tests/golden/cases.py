@@ -139,6 +139,8 @@ F4_CASES = {
     "interp_bilinear_up2": (2, 32, 7, 9),
     "interp_bilinear_noalign_size": (1, 16, 6, 7),
     "interp_nearest_up2": (2, 24, 5, 6),
+    "interp_nearest_ignores_up_false": (1, 16, 6, 5),          # reference tutti.py:232-238: F.interpolate(scale_factor=...) - `up` is not consulted
+    "interp_nearest_ignores_out_size": (1, 8, 4, 7),           # ... nor `out_size`
     "interp_bilinear_down2": (1, 24, 12, 10),
     "concurrent_cat": (2, 32, 10, 10),
     "concurrent_cat_pool": (2, 32, 9, 11),
@@ -159,6 +161,10 @@ def build_f4_block(name, ns):
         return ns.InterpolationBlock(scale_factor=None, out_size=(13, 10), align_corners=False)
     if name == "interp_nearest_up2":
         return ns.InterpolationBlock(scale_factor=2, mode="nearest", align_corners=None)
+    if name == "interp_nearest_ignores_up_false":
+        return ns.InterpolationBlock(scale_factor=2, mode="nearest", align_corners=None, up=False)
+    if name == "interp_nearest_ignores_out_size":
+        return ns.InterpolationBlock(scale_factor=3, out_size=(5, 5), mode="nearest", align_corners=None)
     if name == "interp_bilinear_down2":
         return ns.InterpolationBlock(scale_factor=2, up=False)
     if name == "concurrent_cat":

@@ -195,7 +195,11 @@ if __name__ == "__main__":
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    sys.path.insert(0, args.ref)
+    sys.path.insert(0, args.ref)                     # in front of the repo root: `pytorchcv` below must be the reference, not the alias
+    import pytorchcv.models.common.conv as _ref_conv
+    # (this repo ships a `pytorchcv` alias package: with the wrong sys.path order the "reference" would be the build's own modules)
+    assert os.path.abspath(_ref_conv.__file__).startswith(os.path.abspath(args.ref) + os.sep), \
+        "pytorchcv resolved to {} - not the reference under {}".format(_ref_conv.__file__, args.ref)
     torch.manual_seed(0)
     if args.only in ("", "blocks"):
         do_blocks()

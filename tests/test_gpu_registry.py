@@ -1,6 +1,7 @@
 """GPU smoke + parity over the wider registry: variants that no golden fixture covers (other depths, widths, input sizes,
 TF-same padding at odd sizes) run through the C ABI with seeded random weights and are compared with the oracle in fp32."""
 
+import os
 import pytest
 import torch
 import util
@@ -125,3 +126,41 @@ def test_every_registry_model_runs_and_is_batch_position_invariant(cuda_device):
         del net, y, y1
         torch.cuda.empty_cache()
     assert len(_models) >= 139 and not bad, bad
+
+
+@pytest.mark.parametrize("case_name", ["conv1x1_relu", "conv3x3_s1", "conv3x3_s2", "conv3x3_dil2", "gconv3x3_g32_cg4"])
+def test_integration_md_stub_runs_and_matches_the_reference_golden(case_name, cuda_device):
+    """The reference-side ctypes stub printed in INTEGRATION.md section 2 is EXECUTED, verbatim (only the library path is made
+    absolute), on a reference-shaped ConvBlock - an object with `.conv` (nn.Conv2d) and `.bn` (nn.BatchNorm2d) holding the
+    golden case's state, which is all of ConvBlock the stub touches (pytorchcv/models/common/conv.py:250-276) - and its fp32 NCHW
+    result is compared with the golden output of the imported reference at the bf16 block bound of tests/test_gpu_blocks.py."""
+    import re
+    import types
+    import torch.nn as nn
+    from pytorchcv_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "INTEGRATION.md")) as f:
+        md = f.read()
+    m = re.search(r"```python\n(# pytorchcv/models/common/_pcv_amd\.py.*?)```", md, re.S)
+    assert m, "the reference-side stub is missing from INTEGRATION.md"
+    code = m.group(1)
+    assert 'ctypes.CDLL("libpcv_amd.so")' in code
+    ns = {}
+    exec(compile(code.replace('ctypes.CDLL("libpcv_amd.so")', "ctypes.CDLL({!r})".format(_lib.LIB_PATH)), "INTEGRATION.md", "exec"), ns)
+    case = [c for c in util.BLOCK_CASES if c["name"] == case_name][0]
+    kw = case["kwargs"]
+    sd, x = util.block_state_and_input(case)
+    conv = nn.Conv2d(kw["in_channels"], kw["out_channels"], 1 if case["kind"] == "conv1x1_block" else 3, stride=kw.get("stride", 1),
+                     padding=kw.get("padding", 0 if case["kind"] == "conv1x1_block" else 1), dilation=kw.get("dilation", 1),
+                     groups=kw.get("groups", 1), bias=False)
+    bn = nn.BatchNorm2d(kw["out_channels"])
+    conv.load_state_dict({k[5:]: v for k, v in sd.items() if k.startswith("conv.")}, strict=True)
+    bn.load_state_dict({k[3:]: v for k, v in sd.items() if k.startswith("bn.")}, strict=True)
+    block = types.SimpleNamespace(conv=conv.to(cuda_device), bn=bn.to(cuda_device).eval())
+    with torch.no_grad():
+        y = ns["convblock_forward"](block, x.to(cuda_device))
+    torch.cuda.synchronize()
+    g = util.block_golden(case)
+    assert y.shape == g.shape and y.dtype == torch.float32
+    d = (y.cpu() - g).abs()
+    assert bool((d <= 4e-2 + 2.0 ** -7 * g.abs()).all()), "stub vs reference golden: max |d| {:.3e}".format(float(d.max()))
