@@ -65,6 +65,9 @@ struct D3Params {
     int stride, Hin, Win;   // 1x1 mode only: output pixel (n, ho, wo) reads input pixel (n, stride ho, stride wo) of an Hin x Win map
                             // (H, W, HW, div_hw, div_w then describe the OUTPUT map)
     uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
+    int dbgflags;           // timing experiments only (pcv_set_tuning("dbg", bits); results are WRONG with any bit set): 1 = output stores
+                            // dropped (out-of-range offsets), 2 = no epilogue at all, 4 = loaders keep the first tile's row table, 8 = compute waves keep the
+                            // first tile's column masks, 16 = row table built at the tile change (A/B of the look-ahead build; results stay right)
 };
 
 // In-kernel stamps (cdna_hip_programming.md section 7): a diagnostic build (-DD3X3_STAMPS) times ONE section per K-step - the
@@ -204,30 +207,66 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     int lb_tile = T.tile0, lb_r = 0, lb_c = 0, lb_slot = 0, lb_g = 0;
     uint32_t pbv[XLW];             // byte offset of the pixel itself (+ this lane's chunk), or 2^31 for a row outside [0, M) / the tile
     uint32_t vmask[2] = {0u, 0u};  // 3 bits per piece (ten per register): image row ho + r - 1 exists, r = 0, 1, 2
-    auto setup_b = [&](int t) __attribute__((always_inline)) {
+    // The table of the NEXT tile is built ahead of the tile change, a third per K-step (`table_step`), into its own registers:
+    // built at the change itself (15 pieces x ~20 VALU in the loader that is just then due to issue the next group) it delayed
+    // every barrier of that K-step - 10-13 us of the 93 us of the 56x56x64 layers (9 K-steps per tile), 3.4 us at 28x28x128.
+    uint32_t pbvN[XLW];
+    uint32_t vmaskN[2] = {0u, 0u};
+    int prep_t = -1, prep_c = 3;   // tile whose table pbvN / vmaskN hold or are building; thirds done (3 = complete)
+    auto table_rows = [&](int t, auto J0c, auto J1c, uint32_t (&pb)[XLW], uint32_t (&vmk)[2]) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
         const int tileP0 = (t / p.nChTiles) * BP;
-        vmask[0] = vmask[1] = 0u;
 #pragma unroll
-        for (int j = 0; j < XLW; ++j) {
+        for (int j = J0; j < J1; ++j) {
             const int u = 8 * (NL * j + lw) + lrow;
             const int m = tileP0 + u - 1;
             uint32_t off = 0x80000000u, vm = 0;
             if (u < BP + 2 && m >= 0 && m < p.M) {
                 const uint32_t n = fastdiv((uint32_t)m, p.div_hw);
-                const uint32_t ho = fastdiv((uint32_t)m - n * (uint32_t)p.HW, p.div_w);
+                const uint32_t rem = (uint32_t)m - n * (uint32_t)p.HW;               // pixel index inside its image
                 if constexpr (ONE) {
-                    const uint32_t wo = (uint32_t)m - n * (uint32_t)p.HW - ho * (uint32_t)p.W;
+                    const uint32_t ho = fastdiv(rem, p.div_w);
+                    const uint32_t wo = rem - ho * (uint32_t)p.W;
                     const uint32_t mi = (n * (uint32_t)p.Hin + ho * (uint32_t)p.stride) * (uint32_t)p.Win + wo * (uint32_t)p.stride;
                     off = (uint32_t)((mi * (uint32_t)p.Cin + (uint32_t)cs * 8u) * 2u);
                     vm = 7u;
                 } else {
                     off = (uint32_t)((m * p.Cin + cs * 8) * 2);
-                    vm = (ho >= 1u ? 1u : 0u) | 2u | ((int)ho + 1 < p.H ? 4u : 0u);
+                    // the rows above / below exist unless the pixel sits in the first / last image row: no second division
+                    vm = (rem >= (uint32_t)p.W ? 1u : 0u) | 2u | (rem + (uint32_t)p.W < (uint32_t)p.HW ? 4u : 0u);
                 }
             }
-            pbv[j] = off;
-            vmask[j / 10] |= vm << (3 * (j % 10));
+            pb[j] = off;
+            vmk[j / 10] = (vmk[j / 10] & ~(7u << (3 * (j % 10)))) | (vm << (3 * (j % 10)));
         }
+    };
+    typedef std::integral_constant<int, 0> T0;
+    typedef std::integral_constant<int, (XLW + 2) / 3> T1;
+    typedef std::integral_constant<int, (2 * XLW + 2) / 3> T2;
+    typedef std::integral_constant<int, XLW> T3;
+    auto setup_b = [&](int t) __attribute__((always_inline)) { table_rows(t, T0{}, T3{}, pbv, vmask); };
+    // One third of the next tile's table per K-step, thirds tied to the K-step's compile-time phase PH (3x3 mode: the filter column)
+    // so that every table register is written at ONE place (with a run-time third the compiler merged the three branches into an
+    // indexed store - the table went to scratch): third 0 at phase 2 (the K-step behind a tile change, which happens at phase 1),
+    // third 1 at phase 0, third 2 at phase 1.
+    auto table_step = [&](auto PHc) __attribute__((always_inline)) {
+        constexpr int PH = decltype(PHc)::value;
+        if (prep_t < 0) return;
+        if constexpr (PH == 2) { if (prep_c == 0) { table_rows(prep_t, T0{}, T1{}, pbvN, vmaskN); prep_c = 1; } }
+        if constexpr (PH == 0) { if (prep_c == 1) { table_rows(prep_t, T1{}, T2{}, pbvN, vmaskN); prep_c = 2; } }
+        if constexpr (PH == 1) { if (prep_c == 2) { table_rows(prep_t, T2{}, T3{}, pbvN, vmaskN); prep_c = 3; } }
+    };
+    auto next_table = [&](int t) __attribute__((always_inline)) {   // tile t becomes the loaders' current tile
+        if (prep_t == t && prep_c == 3 && !(p.dbgflags & 16)) {
+#pragma unroll
+            for (int j = 0; j < XLW; ++j) pbv[j] = pbvN[j];
+            vmask[0] = vmaskN[0];
+            vmask[1] = vmaskN[1];
+        } else {
+            setup_b(t);                                         // tiles shorter than three K-steps: built on the spot
+        }
+        prep_t = t + T.tstride < T.tend ? t + T.tstride : -1;
+        prep_c = 0;
     };
     auto dma_b = [&](auto J0c, auto J1c) __attribute__((always_inline)) {                // pieces [J0, J1) of the group
         constexpr int J0 = decltype(J0c)::value, J1 = decltype(J1c)::value;
@@ -248,7 +287,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
             if (ONE || ++lb_r == 3) {
                 lb_r = 0;
                 lb_tile += T.tstride;
-                if (lb_tile < T.tend) setup_b(lb_tile);
+                if (lb_tile < T.tend && !(p.dbgflags & 4)) next_table(lb_tile);
             }
         }
     };
@@ -262,6 +301,8 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
     // prologue: weight tiles of K-steps 0 and 1, activation tile of group 0, the zero row
     setup_a(T.tile0);
     setup_b(T.tile0);
+    prep_t = T.tile0 + T.tstride < T.tend ? T.tile0 + T.tstride : -1;
+    prep_c = 0;
     if (lw < 2) *reinterpret_cast<__attribute__((address_space(3))) u32x4*>((size_t)(lds0 + G::ZOFF + (lw * 64 + lane) * 16)) = (u32x4){0u, 0u, 0u, 0u};
     dma_b(C0{}, CBN{});
     advance_b();
@@ -289,6 +330,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
         if constexpr (Q == 0) { if (moreB) dma_b(C0{}, CB0{}); }
         if constexpr (Q == 1) { if (moreB) { dma_b(CB0{}, CBN{}); advance_b(); } }
         if (moreA) dma_a(C0{}, CA0{});
+        table_step(Qc);                                         // (behind this interval's pieces, in front of its barrier)
         d3q_sync();
         if constexpr (KS == 1) d3q_sync();
         if (moreA) {
@@ -365,16 +407,24 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
     const uint32_t afrag = lds0 + (uint32_t)((wc * 16 * CBW + fr) * 128);
     const uint32_t brow0 = (uint32_t)(wp * 16 * PBW + fr);
     uint32_t hm0 = 0, hm2 = 0;     // bit j: this lane's output pixel of block j is in image column 0 / W - 1 (set per tile)
-    auto setup_masks = [&](int t) __attribute__((always_inline)) {
+    uint32_t hmN = 0;              // the same two masks of the NEXT tile (hm0 in bits 0-15, hm2 in bits 16-31), computed during this tile's
+                                   // last K-step beside the BN prefetch: at the tile change itself it stood between two tiles' K loops
+    auto masks_of = [&](int t) __attribute__((always_inline)) -> uint32_t {
         const int m0 = (t / p.nChTiles) * BP + wp * 16 * PBW + fr;
-        hm0 = hm2 = 0;
+        uint32_t h = 0;
 #pragma unroll
         for (int j = 0; j < PBW; ++j) {
             const uint32_t m = (uint32_t)(m0 + 16 * j);
             const uint32_t wo = m - fastdiv(m, p.div_w) * (uint32_t)p.W;              // (n H + ho) W + wo = m
-            hm0 |= (wo == 0u ? 1u : 0u) << j;
-            hm2 |= (wo + 1u == (uint32_t)p.W ? 1u : 0u) << j;
+            h |= (wo == 0u ? 1u : 0u) << j;
+            h |= (wo + 1u == (uint32_t)p.W ? 1u : 0u) << (16 + j);
         }
+        return h;
+    };
+    auto setup_masks = [&](int t) __attribute__((always_inline)) {
+        const uint32_t h = masks_of(t);
+        hm0 = h & 0xFFFFu;
+        hm2 = h >> 16;
     };
     // section h (of 2 / KS) of K-step (A slot sa, B slot sb, filter column Q): K-halves h * KS .. h * KS + KS - 1.
     // Fragment i / j sits i / j * 2048 bytes behind the wave's first row: pointer arithmetic, so that the constant folds into the
@@ -443,6 +493,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         }
     };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
+        if (p.dbgflags & 2) return;
         const int chTile = t % p.nChTiles;
         const int tileP0 = (t / p.nChTiles) * BP;
         const int mBase = tileP0 + wp * 16 * PBW + fr;
@@ -485,7 +536,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-                const bool ok = chok && m < p.M;
+                const bool ok = chok && m < p.M && !(p.dbgflags & 1);
                 const uint32_t boff = ok ? (uint32_t)(((size_t)m * p.Ypitch + ch0) * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
             }
@@ -516,12 +567,18 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 epilogue(ep_tile);
                 zero_acc();
                 if constexpr (!ONE) {
-                    if (s < K_total) setup_masks(cur_tile);
+                    if (!(p.dbgflags & 8)) {
+                        hm0 = hmN & 0xFFFFu;
+                        hm2 = hmN >> 16;
+                    }
                 }
             }
             if (s == K_total) return true;
         }
-        if (k == nk - 1) ep_prefetch(cur_tile);
+        if (k == nk - 1) {
+            ep_prefetch(cur_tile);
+            if constexpr (!ONE) hmN = masks_of(cur_tile + T.tstride);               // (past the last tile: computed, never used)
+        }
         if constexpr (GRP == 0) {
             reads(sa, sb, Qc, 0);
             reads_done();

@@ -50,6 +50,7 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
+    int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
     int dw_flags = 0;           // tuning: bit 0 = non-temporal stores in the depthwise kernels
     int dw_th = 0;              // tuning: rows per thread of the depthwise kernel (0 = automatic)
     int max_blocks = 0;         // test-only: cap on every persistent grid (0 = resident blocks), so that small fixtures walk several
@@ -777,6 +778,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d1x1") ctx->use_d1x1 = value;
     else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
+    else if (k == "dbg") ctx->dbg_flags = value;
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
     else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;
@@ -1193,7 +1195,7 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     D3Params q;
     std::memset(&q, 0, sizeof(q));
     q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
-    q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf; q.dbgflags = ctx->dbg_flags;
     q.x_bytes = (uint32_t)G.xbytes; q.w_bytes = (uint32_t)P.w_bytes; q.y_bytes = (uint32_t)ybytes;
     q.res_bytes = (uint32_t)(G.M64 * (unsigned long long)d->Cout * 2ull);
     q.M = (int)G.M64; q.Cout = d->Cout; q.Ypitch = ypitch; q.Cin = d->Cin; q.Kpad = P.Kpad;
