@@ -47,6 +47,7 @@ struct pcv_ctx {
     int use_gconvr = 1;         // grouped 3x3 stride 2 / 32 channels per group on the row-tile kernel (gconv3x3r.hpp); 0 = generic implicit GEMM
     int use_d1x1 = -1;          // K-heavy 1x1 layers on d3q_kernel's 1x1 mode: -1 = pick_d1x1, 0 = never, n > 0 = force shape n - 1 where eligible
     int use_head = 1;           // fp32 dense layers on 1x1 maps run head_gemm.hpp (0: the generic implicit-GEMM tiles)
+    int use_stem32 = 1;         // stems with <= 32 output channels run the 32-row form of the stem kernel (0: the 64-row form; A/B, tests)
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
@@ -473,6 +474,13 @@ static int enable_stem(pcv_ctx* ctx) {
                                 reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, true, true>)};
     for (int i = 0; i < 4; ++i)
         HIP_TRY(ctx, hipFuncSetAttribute(from_nchw[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds + kStemStageBytes));
+    // the 32-channel form (stems with at most 32 output channels, no fused pool)
+    const void* narrow[4] = {reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, false, false, 2>),
+                             reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, false, false, 2>),
+                             reinterpret_cast<const void*>(stem_conv_kernel<PCV_BF16, false, true, 2>),
+                             reinterpret_cast<const void*>(stem_conv_kernel<PCV_F16, false, true, 2>)};
+    for (int i = 0; i < 4; ++i)
+        HIP_TRY(ctx, hipFuncSetAttribute(narrow[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds + (i >= 2 ? kStemStageBytes : 0)));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, kStemLds));
         int nb = 0;
@@ -775,6 +783,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "head") ctx->use_head = value;
+    else if (k == "stem32") ctx->use_stem32 = value;
     else if (k == "d1x1") ctx->use_d1x1 = value;
     else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
@@ -1115,7 +1124,15 @@ static int launch_stem(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, 
     const bool bf = d->dtype == PCV_BF16;
     const dim3 g((unsigned)nb), b(256);
     hipStream_t st = A.stream;
-    if (x_nchw) {
+    const bool narrow = !pool && d->Cout <= 32 && ctx->use_stem32;             // half the channel rows: stems of the MobileNet / EfficientNet families
+    if (narrow && x_nchw) {
+        const int lds = kStemLds + kStemStageBytes;
+        if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false, true, 2>), g, b, lds, st, q);
+        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false, true, 2>), g, b, lds, st, q);
+    } else if (narrow) {
+        if (bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, false, false, 2>), g, b, kStemLds, st, q);
+        else hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, false, false, 2>), g, b, kStemLds, st, q);
+    } else if (x_nchw) {
         const int lds = kStemLds + kStemStageBytes;
         if (pool && bf) hipLaunchKernelGGL((stem_conv_kernel<PCV_BF16, true, true>), g, b, lds, st, q);
         else if (pool) hipLaunchKernelGGL((stem_conv_kernel<PCV_F16, true, true>), g, b, lds, st, q);

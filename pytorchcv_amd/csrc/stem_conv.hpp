@@ -59,8 +59,10 @@ __device__ __forceinline__ uint32_t stem_pkmax(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
 
-// 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 64 (padded) channels.
-template <int DT, bool POOL = false, bool NCHW = false>
+// 256 threads: wave w computes output rows 4w..4w+3 of the 16x16 tile, all 16 CB (padded) channels. CB = 4: up to 64 output
+// channels; CB = 2: up to 32 (the 3x3 / 2 stems of MobileNetV2 / V3 / EfficientNet: half the MFMAs and half the epilogue of the
+// 64-row form, whose upper 32 rows multiplied zero weights there).
+template <int DT, bool POOL = false, bool NCHW = false, int CB = 4>
 __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = 16, TW = 16;
@@ -182,9 +184,10 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
     const int wfrag = fr * 64 + ((fq ^ wf) << 4);                // + r*4096 + i*1024
     const int xfrag = (fr + fq) * 16;                            // + (2*orow + r) * PCH*16
 
-    float sc[2][8], sf[2][8];
+    static_assert(CB == 4 || (CB == 2 && !POOL), "the pooled stem (ResNet-style init blocks) has 64 channels");
+    float sc[CB / 2][8], sf[CB / 2][8];
 #pragma unroll
-    for (int ip = 0; ip < 2; ++ip) {
+    for (int ip = 0; ip < CB / 2; ++ip) {
         const int ch0 = 32 * ip + 8 * fq;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -212,21 +215,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         }
         if (has_next) issue_patch(ntile, buf ^ 1);
 
-        f32x4 acc[4][4];
+        f32x4 acc[CB][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* pbase = smem + WBYTES + (NCHW ? 0 : buf) * PBYTES + xfrag;
         for (int r = 0; r < p.kh; ++r) {
-            frag a[4], b[4];
+            frag a[CB], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const frag*>(smem + r * 4096 + i * 1024 + wfrag);
+            for (int i = 0; i < CB; ++i) a[i] = *reinterpret_cast<const frag*>(smem + r * 4096 + i * 1024 + wfrag);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 b[j] = *reinterpret_cast<const frag*>(pbase + (2 * (4 * wave + j) + r) * (PCH * 16));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < CB; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
         }
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         } else {
         const int wo = tw * TW + fr;
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
+        for (int ip = 0; ip < CB / 2; ++ip) {
             const int ch0 = 32 * ip + 8 * fq;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

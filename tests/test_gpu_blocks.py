@@ -636,3 +636,30 @@ def test_stem_from_nchw_equals_layout_kernel_plus_stem(shape, kind, dtype, grid,
         y_two = blk(engine.from_nchw(x, dtype, stem=True))
     torch.cuda.synchronize()
     assert y_direct.t.shape == y_two.t.shape and torch.equal(y_direct.t, y_two.t)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("cout,k", [(32, 3), (16, 3), (24, 3), (32, 5), (8, 7)])
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 33, 35), (1, 64, 28)])
+def test_stem_32_channel_form_equals_64_row_form(shape, cout, k, dtype, grid, cuda_device):
+    """Stems with at most 32 output channels (MobileNetV2 / V3, EfficientNet: `conv3x3_block(3, 32, stride=2)`, reference
+    mobilenetv2.py:121-125) run stem_conv_kernel<..., CB = 2> - half the accumulator rows and half the epilogue of the 64-row form.
+    Same MFMA sequence per accumulator, same epilogue arithmetic: bit-identical to the 64-row form (pcv_set_tuning("stem32", 0)), from
+    the fp32 NCHW image and from the NHWC4 tensor."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import ConvBlock
+    N, H, W = shape
+    blk = ConvBlock(in_channels=3, out_channels=cout, kernel_size=k, stride=2, padding=k // 2).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=4))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, 3, H, W, seed=14).to(cuda_device)
+    outs = {}
+    with torch.no_grad():
+        for sw in (0, 1):
+            with util.tuning(max_blocks=grid, stem32=sw):
+                outs[sw] = (blk(engine.network_input(x, dtype)).t.clone(), blk(engine.from_nchw(x, dtype, stem=True)).t.clone())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[1][0].float()).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][0], outs[1][1])
