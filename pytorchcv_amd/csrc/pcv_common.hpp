@@ -37,6 +37,20 @@ __device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
     h2 r = __builtin_convertvector(v, h2);
     return *reinterpret_cast<uint32_t*>(&r);
 }
+// fp16 only: round the pair FIRST, then clamp the packed pair to [0, upper] (upper = two fp16 values, e.g. 0x46004600 = 6.0) with
+// v_pk_maximum3_f16 / v_pk_minimum3_f16 - two instructions for two values where the fp32 clamp takes four. Same bits as clamping
+// in fp32 and rounding afterwards: rounding is monotonic and 0 / 6 are fp16 values (a value beyond fp16's range rounds to +-inf and
+// is clamped to upper / 0 like its fp32 original); both forms propagate NaN (IEEE-754-2019 maximum / minimum).
+__device__ __forceinline__ uint32_t pack2_clamp_f16(float lo, float hi, uint32_t upper) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    f2 v = {lo, hi};
+    h2 r = __builtin_convertvector(v, h2);
+    const h2 zero = {(_Float16)0.f, (_Float16)0.f};
+    r = __builtin_elementwise_maximum(r, zero);
+    r = __builtin_elementwise_minimum(r, __builtin_bit_cast(h2, upper));
+    return __builtin_bit_cast(uint32_t, r);
+}
 template <int DT> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     if constexpr (DT == PCV_BF16) return pack2_bf16(lo, hi);
     else return pack2_f16(lo, hi);
