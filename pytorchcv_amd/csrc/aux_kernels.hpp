@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         v[e] = (c < C && w < W) ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f;
     }
     const size_t eoff = (size_t)pix * cpitch + c0;
-    F16Guard<OT, false> guard;                                          // an image value beyond fp16's range
+    F16Guard<OT> guard;                                          // an image value beyond fp16's range
     guard.see(v);
     guard.commit(ovf);
     if (cpitch - c0 >= 8) {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const void* __restrict__ 
                                                       int HW, int C, int post_act, uint32_t* __restrict__ ovf) {
     const int C8 = C / 8;
     const ActClamp pact = make_act(post_act);
-    F16Guard<DT, false> guard;
+    F16Guard<DT> guard;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         const long pix = i / C8;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const void* __restrict__ x,
                                                     int C, int xpitch, int act_code, uint32_t* __restrict__ ovf) {
     const int C8 = C / 8;
     const ActClamp act = make_act(act_code);
-    F16Guard<DT, false> guard;
+    F16Guard<DT> guard;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % C8) * 8;
         float v[8], a[8], b[8];
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char*
         for (int c = 0; c < C && c < 4; ++c) v[c] = ((float)src[c] * (1.f / 255.f) - mean[c]) * inv_std[c];
     }
     const size_t eoff = (size_t)pix * cpitch;
-    F16Guard<OT, false> guard;
+    F16Guard<OT> guard;
     guard.see(v);
     guard.commit(ovf);
     if constexpr (OT == PCV_F32) {

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
 
     int ho = ho_begin;
     int hi = hi_first;
-    F16Guard<DT, false> guard;
+    F16Guard<DT> guard;
     const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && act_bounded(p.act));
     while (ho < ho_end) {
         static_for<KS>([&](auto PHC) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
         for (int e = 0; e < NV; ++e) { sc[e] = (f32x2){a4[2 * e], a4[2 * e + 1]}; sf[e] = (f32x2){b4[2 * e], b4[2 * e + 1]}; }
     }
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
-    F16Guard<DT, false> guard;
+    F16Guard<DT> guard;
     const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && act_bounded(p.act));
 
     const int wi0 = wo * S - p.pl;

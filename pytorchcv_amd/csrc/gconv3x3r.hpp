@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gconv3x3r_kernel(const GConvRParams p)
         // ---- epilogue: MFMA rows 4 fq + e of slab i = channels 64 cb + 16 i + 4 fq + e, output pixel g0 Wo + ml: 8-byte stores ----
         const int m = g0 * p.Wo + ml;
         const bool ok = lvalid && m < p.Mout;
-        F16Guard<DT, false> guard;
+        F16Guard<DT> guard;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = cb * 64 + 16 * i + 4 * fq;

@@ -285,7 +285,6 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
     };
 
     const ActClamp act = make_act(p.act), pact = make_act(p.post_act);
-    F16Guard<OT> guard;
     // the stored value is bounded by construction (no range check needed) when the last thing applied to it is a bounded activation
     const bool bounded = act_bounded(p.post_act) || (p.post_act == PCV_ACT_NONE && p.res == nullptr && p.gate == nullptr && act_bounded(p.act));
     zero_acc();
@@ -366,6 +365,7 @@ __global__ __launch_bounds__(64 * WC * WP, 2) void igemm_conv_kernel(const Igemm
         compute(buf);
 
         // ---- epilogue: scale/shift -> act -> (+residual) -> post_act -> NHWC store ----------------------------
+        F16Guard<OT> guard;                                     // (its scalar state lives in the epilogue only, not across the K loop)
 #pragma unroll
         for (int ip = 0; ip < NPAIR; ++ip) {
             const int ch0 = chBlk + 32 * ip + 8 * fq;           // within the group-block

@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
     }
 
     const ActClamp act_e = make_act(p.act_e), act_d = make_act(p.act_d), act_p = make_act(p.act_p), post = make_act(p.post);
-    F16Guard<DT> guard;
 
     // ---- LDS-DMA of 32 channels [c0, c0 + 32) of tile t's input window into `dst` (same slab scheme, rows = pixels) ----------
     auto dma_tile = [&](int t, char* dst, int c0) {
@@ -227,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
             for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         for (int c = 0; c < p.nChunks; ++c) {
+            F16Guard<DT> g1, g2;                                // fp16 range checks of this chunk's E / D values
             char* const Ec = EXPAND ? Es : Es + (c & 1) * ESZ;
             // ---- S1: E chunk ------------------------------------------------------------------------------------------------
             if constexpr (EXPAND) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
                             v[4 + e] = ea[m][1][e] * se1[e] + he1[e];
                         }
                         apply_act8(v, act_e);
-                        if (!act_bounded(p.act_e)) guard.see(v);
+                        if (!act_bounded(p.act_e)) g1.see(v);
                         const bool ok = valid[ip] != 0;
                         u32x4 o;
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = da[e] * sd[e] + hd[e];
                     apply_actn<4>(v, act_d);
-                    if (!act_bounded(p.act_d)) guard.see(v);
+                    if (!act_bounded(p.act_d)) g2.see(v);
                     u32x2 o;
                     o[0] = pack2<DT>(v[0], v[1]);
                     o[1] = pack2<DT>(v[2], v[3]);
@@ -320,6 +320,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
             }
             __syncthreads();
 
+            g1.commit(p.ovf);
+            g2.commit(p.ovf);
             // ---- S3: project GEMM, K-step = this chunk --------------------------------------------------------------------------
             {
                 frag wp[MAXRT];
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_kernel(const MbParams p) {
         }
 
         // ---- epilogue: BN (+ residual), 16-byte NHWC stores --------------------------------------------------------------------
+        F16Guard<DT> guard;
 #pragma unroll
         for (int ipp = 0; ipp < MAXRT / 2; ++ipp) {
             if (2 * ipp < p.nRowT) {

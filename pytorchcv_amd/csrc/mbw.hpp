@@ -103,7 +103,6 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
     // VALU instructions of one S1 pixel block between two MFMA groups (BN 4 packed fma, 16 clamps, 4 packs, address / select) - the
     // fp16 ReLU build checks the rounded range on top (F16Guard: 4 x v_max(3)_f32 + v_cmp)
     constexpr int S1VALU = (DT == PCV_F16 && ACT == PCV_ACT_RELU6) ? 14 : 26 + ((DT == PCV_F16 && ACT == PCV_ACT_RELU) ? 5 : 0);   // (4 pk_fma + 4 cvt + 8 packed clamps)
-    F16Guard<DT> guard;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nWaves = blockDim.x >> 6;
     constexpr bool WLDS = KA == 1;                      // 1x1 weights resident in LDS (else: fragments straight from L2)
@@ -256,6 +255,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
 
 #pragma unroll 1
         for (int c = 0; c < p.nChunks; ++c) {
+            F16Guard<DT, true> g1, g2;                                // fp16 range checks of this chunk's E / D values (unbounded activations only)
             // ---- S1: E chunk over the whole window ---------------------------------------------------------------------------------
             {
                 frag we[KA][2];
@@ -310,12 +310,12 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                         const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), hi);
-                        if constexpr (ACT != PCV_ACT_RELU6) guard.see(v);          // (ReLU6: bounded by construction)
+                        if constexpr (ACT != PCV_ACT_RELU6) g1.see(v);             // (ReLU6: bounded by construction)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
                     } else {
                         apply_act8(v, act_e);
-                        guard.see(v);
+                        g1.see(v);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = ok ? pack2<DT>(v[2 * e], v[2 * e + 1]) : 0u;
                     }
@@ -376,12 +376,16 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
                         o[1] = pack2_clamp_f16(v[2], v[3], 0x46004600u);
                     } else {
                         mbw_act<ACT, 4>(v, act_d);
-                        if constexpr (ACT != PCV_ACT_RELU6) guard.see(v);
+                        if constexpr (ACT != PCV_ACT_RELU6) g2.see(v);
                         o[0] = pack2<DT>(v[0], v[1]);
                         o[1] = pack2<DT>(v[2], v[3]);
                     }
                     *reinterpret_cast<u32x2*>((g == 0 ? d_wr0 : d_wr1) + (16 * u) * PITCH) = o;
                 }
+            }
+            if constexpr (ACT != PCV_ACT_RELU6) {
+                g1.commit(p.ovf);
+                g2.commit(p.ovf);
             }
             // ---- S3: project GEMM, K step = this chunk ---------------------------------------------------------------------------------
             {
@@ -401,6 +405,7 @@ __global__ __launch_bounds__(512) void mbw_kernel(const MbParams p) {
         }
 
         // ---- epilogue: BN (+ residual), 16-byte NHWC stores ---------------------------------------------------------------------------
+        F16Guard<DT, true> guard;
 #pragma unroll
         for (int ipp = 0; ipp < NRT / 2; ++ipp) {
             const int ch = 32 * ipp + 8 * fq;

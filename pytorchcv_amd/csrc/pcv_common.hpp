@@ -81,21 +81,27 @@ template <int DT> __device__ __forceinline__ void store_elem(void* base, size_t 
 // ---- fp16 range guard ------------------------------------------------------------------------------------
 // fp16 storage rounds |v| >= 65520 to infinity, and a ReLU6 / sigmoid / h-sigmoid behind it clamps that infinity back into
 // range: an overflow inside a net would come out as plausible finite logits. So every kernel that rounds fp32 results to fp16
-// checks the magnitudes it rounds (one v_max3_f32 per two values + one compare per group; NaNs are ignored - they propagate by
-// themselves) and bumps the context's overflow counter when one crossed fp16's range. pcv_fp16_guard_begin / _end
+// checks the magnitudes it rounds (one v_max3_f32 per two values; NaNs are ignored - they propagate by themselves) and bumps the context's overflow counter when one crossed fp16's range. pcv_fp16_guard_begin / _end
 // (include/pcv_amd.h) turn a counter change during a forward into NaN logits. Compiled out for bf16 / fp32 storage.
-//   UNIFORM (the MFMA kernels, whose epilogues run in wave-uniform control flow): the verdict of a group is a wave ballot OR-ed
-//   into a scalar register pair - no vector register lives across the kernel's loops (a per-lane running maximum spilled 140-320
-//   bytes in the register-bound fused-unit kernels).
-//   !UNIFORM (per-thread loops with divergent trip counts: depthwise, elementwise): a per-lane running maximum.
+//   A guard object is STAGE-LOCAL: declared where a kernel starts rounding a batch of results (an epilogue, one chunk of a fused
+//   unit) and `commit()`ted at the end of that stage - one atomic from one lane if anything crossed the range. Two forms, measured
+//   per kernel (MobileNetV3-large, fp16 against bf16, rocprofv3):
+//     SCALAR = false: a per-lane running maximum in ONE vector register, one wave ballot at commit (4 VALU per eight values). The
+//       default: generic / stem / depthwise / elementwise kernels (igemm h-swish layers +5 % against +9 % with the scalar form).
+//     SCALAR = true: the verdict of every group is a wave ballot OR-ed into a scalar register pair - no vector state at all, one
+//       compare more per group. For the register-bound fused-unit kernels (mbw.hpp: 233-256 registers): there the extra vector
+//       register of the other form spilled inside the chunk loop (the wide dynamic-activation instance +45 % instead of +5 %).
+//   (Declared at kernel scope instead of per stage, either form lived across the K loops and spilled 140-320 bytes.)
 constexpr float kF16Overflow = 65520.f;
-template <int OT, bool UNIFORM = true> struct F16Guard {
+template <int OT, bool SCALAR = false> struct F16Guard {
     float m;
     unsigned long long hit;
     __device__ __forceinline__ F16Guard() : m(0.f), hit(0ull) {}
     __device__ __forceinline__ void note(float t) {
-        if constexpr (UNIFORM) hit |= __builtin_amdgcn_ballot_w64(t >= kF16Overflow);
+#ifndef PCV_NO_F16_GUARD      // timing experiments only (make EXTRA=-DPCV_NO_F16_GUARD): what the range check costs
+        if constexpr (SCALAR) hit |= __builtin_amdgcn_ballot_w64(t >= kF16Overflow);
         else m = fmaxf(m, t);
+#endif
     }
     __device__ __forceinline__ void see2(float a, float b) {
         if constexpr (OT == PCV_F16) note(fmaxf(fabsf(a), fabsf(b)));
@@ -109,18 +115,16 @@ template <int OT, bool UNIFORM = true> struct F16Guard {
             note(t);
         }
     }
-    // `live` (!UNIFORM only): false for a lane whose values are never stored and may be garbage
+    // `live`: false for a lane whose values are never stored and may be garbage (per-lane form only)
     __device__ __forceinline__ void commit(uint32_t* counter, bool live = true) {
         if constexpr (OT == PCV_F16) {
-            if constexpr (UNIFORM) {
-                if (hit != 0ull && counter != nullptr) {
-                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(counter, 1u);
-                }
-                hit = 0ull;
-            } else {
-                if (live && m >= kF16Overflow && counter != nullptr) atomicAdd(counter, 1u);
-                m = 0.f;
+            const unsigned long long h = SCALAR ? hit : __builtin_amdgcn_ballot_w64(live && m >= kF16Overflow);
+            if (h != 0ull && counter != nullptr) {
+                const unsigned active = (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));      // one lane of those here
+                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == active) atomicAdd(counter, 1u);
             }
+            m = 0.f;
+            hit = 0ull;
         }
     }
 };

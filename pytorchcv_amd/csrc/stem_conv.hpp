@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(dst0 + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
         }
     };
-    F16Guard<DT> guard;
+    F16Guard<DT> guard;                                           // (reset by commit() at the end of every tile)
     // NCHW: staged fp32 planes of tile t -> the 16-bit NHWC4 patch (buffer 0): item c = 256 j + tid = (patch row, pixel pair)
     auto convert_patch = [&](int t) {
         const int tw = t % p.tilesW;
