@@ -29,7 +29,7 @@ extern "C" {
 
 /* 2: pcv_conv_desc starts with struct_size and ends with y_cpitch (version 1 had neither check; a binding built against
  * another layout is refused with PCV_ERR_INVALID instead of being read past its end)
- * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count (no layout change) */
+ * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count, + pcv_rccl_* (no layout change) */
 #define PCV_ABI_VERSION 3
 
 typedef struct pcv_ctx pcv_ctx;
@@ -261,6 +261,20 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
  * y is dense. */
 int pcv_bn_act(pcv_ctx* ctx, const void* x, const float* scale, const float* shift, void* y, long rows, int C,
                int x_cpitch, int act, int dtype, void* stream);
+
+/* ---- multi-GPU: RCCL helpers for a C caller -------------------------------------------------------------------------------------
+ * The reference has no distributed code; BASELINE's north star shards the batch over the 8 GPUs of a node - one
+ * process per GPU, the packed weights broadcast once over xGMI, the logits gathered per batch, no collective between layers. The
+ * Python package does this through torch.distributed (pytorchcv_amd/parallel.py); these three entry points are the same two
+ * collectives for a caller that only has this ABI. `comm` is the caller's communicator (an ncclComm_t from ncclCommInitRank, passed
+ * as void*); the RCCL entry points are resolved at run time from the librccl the process already has (PyTorch's or the caller's; else
+ * dlopen("librccl.so.1")) - the library has no link-time dependency on RCCL. All calls are asynchronous on `stream`. */
+int pcv_rccl_available(void);                       /* 1 when ncclBroadcast / ncclAllGather / ncclGroupStart / ncclGroupEnd resolve */
+/* bufs[i] (device, bytes[i] long, same sizes on every rank) becomes rank `root`'s: ONE grouped RCCL launch for all `count` buffers -
+ * xGMI is point-to-point, a ring broadcast is per-link bound, so few large messages (pcv_conv_pack's blobs, the folded scale/shift). */
+int pcv_rccl_broadcast(pcv_ctx* ctx, void* comm, void* const* bufs, const size_t* bytes, int count, int root, void* stream);
+/* recv[r * bytes_per_rank ...] = rank r's `send`: the fp32 logits of every rank's image shard, in rank order (4 KB per image). */
+int pcv_rccl_allgather(pcv_ctx* ctx, void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,9 @@ _SIGS = {
     "pcv_fp16_guard_begin": (_I, [_VP, _VP, _VP]),
     "pcv_fp16_guard_end": (_I, [_VP, _VP, _VP, ctypes.c_long, _VP]),
     "pcv_fp16_overflow_count": (_I, [_VP, ctypes.POINTER(ctypes.c_uint), _VP]),
+    "pcv_rccl_available": (_I, []),
+    "pcv_rccl_broadcast": (_I, [_VP, _VP, ctypes.POINTER(_VP), ctypes.POINTER(ctypes.c_size_t), _I, _I, _VP]),
+    "pcv_rccl_allgather": (_I, [_VP, _VP, _VP, _VP, ctypes.c_size_t, _VP]),
     "pcv_nchw_to_nhwc": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_nhwc_to_nchw": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _VP]),
     "pcv_preprocess_u8": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _I, _VP]),

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "d3q_inst.hpp"
@@ -823,6 +824,76 @@ int pcv_fp16_guard_end(pcv_ctx* ctx, const unsigned* slot, float* y, long count,
     const unsigned grid = (unsigned)std::min<long>((count + 255) / 256, 1024);
     f16_guard_end_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(ctx->ovf, slot, y, count);
     HIP_TRY(ctx, hipGetLastError());
+    return PCV_OK;
+}
+
+// ---- RCCL helpers (resolved at run time: no link-time dependency) ----------------------------------------------
+extern "C++" {
+namespace {
+typedef int (*nccl_group_fn)(void);
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*nccl_err_fn)(int);
+struct RcclApi {
+    nccl_group_fn group_start = nullptr, group_end = nullptr;
+    nccl_bcast_fn broadcast = nullptr;
+    nccl_gather_fn allgather = nullptr;
+    nccl_err_fn error_string = nullptr;
+    bool ok = false;
+};
+const RcclApi& rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        // the librccl this process already has (by SONAME: also finds one that PyTorch loaded privately), else load one
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW);
+        if (!h) return a;
+        a.group_start = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupStart"));
+        a.group_end = reinterpret_cast<nccl_group_fn>(dlsym(h, "ncclGroupEnd"));
+        a.broadcast = reinterpret_cast<nccl_bcast_fn>(dlsym(h, "ncclBroadcast"));
+        a.allgather = reinterpret_cast<nccl_gather_fn>(dlsym(h, "ncclAllGather"));
+        a.error_string = reinterpret_cast<nccl_err_fn>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.group_start && a.group_end && a.broadcast && a.allgather;
+        return a;
+    }();
+    return api;
+}
+const int kNcclUint8 = 1;        // ncclUint8 / ncclChar = 0 or 1 in nccl.h: both are one byte per element
+int rccl_fail(pcv_ctx* ctx, const char* what, int rc) {
+    const RcclApi& R = rccl_api();
+    return fail(ctx, PCV_ERR_HIP, std::string(what) + ": " + (R.error_string ? R.error_string(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+}  // namespace
+}  // extern "C++"
+
+int pcv_rccl_available(void) { return rccl_api().ok ? 1 : 0; }
+
+int pcv_rccl_broadcast(pcv_ctx* ctx, void* comm, void* const* bufs, const size_t* bytes, int count, int root, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!comm || !bufs || !bytes || count <= 0 || root < 0) return fail(ctx, PCV_ERR_INVALID, "pcv_rccl_broadcast: bad argument");
+    for (int i = 0; i < count; ++i)
+        if (!bufs[i] || bytes[i] == 0) return fail(ctx, PCV_ERR_INVALID, "pcv_rccl_broadcast: NULL or empty buffer");
+    const RcclApi& R = rccl_api();
+    if (!R.ok) return fail(ctx, PCV_ERR_INVALID, "pcv_rccl_broadcast: no RCCL in this process (librccl.so.1 not found)");
+    int rc = R.group_start();
+    if (rc != 0) return rccl_fail(ctx, "ncclGroupStart", rc);
+    for (int i = 0; i < count && rc == 0; ++i) rc = R.broadcast(bufs[i], bufs[i], bytes[i], kNcclUint8, root, comm, (hipStream_t)stream);
+    const int rc_end = R.group_end();
+    if (rc != 0) return rccl_fail(ctx, "ncclBroadcast", rc);
+    if (rc_end != 0) return rccl_fail(ctx, "ncclGroupEnd", rc_end);
+    return PCV_OK;
+}
+
+int pcv_rccl_allgather(pcv_ctx* ctx, void* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+    if (!ctx) return PCV_ERR_INVALID;
+    DeviceGuard device_guard(ctx->device);
+    if (!comm || !send || !recv || bytes_per_rank == 0) return fail(ctx, PCV_ERR_INVALID, "pcv_rccl_allgather: bad argument");
+    const RcclApi& R = rccl_api();
+    if (!R.ok) return fail(ctx, PCV_ERR_INVALID, "pcv_rccl_allgather: no RCCL in this process (librccl.so.1 not found)");
+    const int rc = R.allgather(send, recv, bytes_per_rank, kNcclUint8, comm, (hipStream_t)stream);
+    if (rc != 0) return rccl_fail(ctx, "ncclAllGather", rc);
     return PCV_OK;
 }
 

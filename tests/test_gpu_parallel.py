@@ -79,3 +79,46 @@ def test_packed_state_broadcast_carries_what_the_kernels_read(name, rccl_group, 
         assert 0.45 * fp32_state < nbytes < 0.60 * fp32_state, (nbytes, fp32_state)  # 51 MB of packed state vs 102 MB of fp32
     with torch.no_grad():
         assert torch.equal(b(x), ya)
+
+
+def test_c_abi_rccl_helpers_world_size_1(cuda_device):
+    """pcv_rccl_broadcast / pcv_rccl_allgather (include/pcv_amd.h: the two collectives of the batch-sharded path for a C caller) on
+    a 1-rank communicator made with RCCL's own C API - the library resolves ncclBroadcast / ncclAllGather from the librccl this
+    process has. At world size 1 both are identities: what is checked is that the entry points reach RCCL with the right
+    arguments (a grouped broadcast of several buffers, byte counts), return 0, and leave the data intact; bad arguments are
+    refused before RCCL is called."""
+    import ctypes
+    from pytorchcv_amd import _lib
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    torch.cuda.set_device(cuda_device)
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0 and comm.value
+    try:
+        L, ctx = _lib.lib(), _lib.ctx_for(0)
+        assert L.pcv_rccl_available() == 1
+        st = ctypes.c_void_p(torch.cuda.current_stream(cuda_device).cuda_stream)
+        g = torch.Generator().manual_seed(3)
+        bufs = [torch.randint(0, 255, (n,), generator=g, dtype=torch.uint8).to(cuda_device) for n in (4096, 17, 1 << 20)] + \
+               [torch.randn(1000, generator=g).to(cuda_device)]
+        want = [b.clone() for b in bufs]
+        ptrs = (ctypes.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+        sizes = (ctypes.c_size_t * len(bufs))(*[b.numel() * b.element_size() for b in bufs])
+        assert L.pcv_rccl_broadcast(ctx, comm, ptrs, sizes, len(bufs), 0, st) == 0, L.pcv_last_error(ctx)
+        y = torch.randn((4, 1000), generator=g).to(cuda_device)
+        out = torch.empty_like(y)
+        assert L.pcv_rccl_allgather(ctx, comm, ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(out.data_ptr()), y.numel() * 4, st) == 0, \
+            L.pcv_last_error(ctx)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(bufs, want)) and torch.equal(out, y)
+        assert L.pcv_rccl_broadcast(ctx, None, ptrs, sizes, len(bufs), 0, st) == -1
+        assert L.pcv_rccl_broadcast(ctx, comm, ptrs, sizes, 0, 0, st) == -1
+        assert L.pcv_rccl_allgather(ctx, comm, None, ctypes.c_void_p(out.data_ptr()), 16, st) == -1
+    finally:
+        rccl.ncclCommDestroy(comm)
