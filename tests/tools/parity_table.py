@@ -6,20 +6,22 @@ import torch, util
 import pytorchcv_amd
 from pytorchcv_amd.model_provider import get_model
 dev = torch.device("cuda", 0)
-print("| model | fp32 | bf16 | fp16 | top-1 (bf16) |")
+print("| model | default mode | fp32 | bf16 | fp16 | top-1 (default mode) |")
 for name in util.MODELS:
     logits, ids = util.model_golden(name)
     x = util.images(ids).to(dev)
     row = []
     top = True
-    for dt in ("fp32", "bf16", "fp16"):
+    mode = None
+    for dt in ("auto", "fp32", "bf16", "fp16"):
         net = get_model(name).eval()
         net.load_state_dict(util.model_state(name, net.state_dict()), strict=True)
         net = pytorchcv_amd.set_compute_dtype(net.to(dev), dt)
         with torch.no_grad():
             y = net(x).float().cpu()
         row.append(float((y - logits).abs().max()))
-        if dt == "bf16":
+        if dt == "auto":
             top = bool(torch.equal(y.argmax(1), logits.argmax(1)))
+            mode = pytorchcv_amd.engine.compute_dtype_of(net)
         del net
-    print("| %s | %.1e | %.1e | %.1e | %s |" % (name, row[0], row[1], row[2], "identical" if top else "DIFFERS"), flush=True)
+    print("| %s | %s %.1e | %.1e | %.1e | %.1e | %s |" % (name, mode, row[0], row[1], row[2], row[3], "identical" if top else "DIFFERS"), flush=True)
