@@ -16,9 +16,9 @@ net = pytorchcv_amd.set_compute_dtype(net.to(dev), "bf16")
 x = synth_input(8, seed=0).to(dev).repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
 recs = []
 orig = engine.ConvRunner._launch
-def timed(self, xx, d, res):
+def timed(self, xx, d, res, *more):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record(); y = orig(self, xx, d, res); e.record()
+    s.record(); y = orig(self, xx, d, res, *more); e.record()
     es = xx.t.element_size()
     cin_g = d.Cin // d.groups
     fl = 2.0 * y.N * y.H * y.W * d.Cout * cin_g * d.kh * d.kw
