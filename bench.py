@@ -341,6 +341,12 @@ class Env(object):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # PCV_BENCH_REHEARSE=1 (dev, a ONE-GPU box): every rank runs the real product path on cuda:0 and the collectives go through gloo -
+        # the N > 1 code path (packed-state broadcast of the real arenas, replica check, MAX-reduced timing) without a second GPU.
+        # Never a measurement: the ranks share one GPU, and the JSON line says so.
+        self.rehearse = not stub and os.environ.get("PCV_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            self.local_rank = 0
         self.dev = torch.device("cpu") if stub else torch.device("cuda", self.local_rank)
         self.use_dist = self.world > 1 or os.environ.get("PCV_BENCH_FORCE_DIST") == "1"   # (forced at world size 1: rehearses the RCCL calls)
         if self.use_dist:
@@ -349,7 +355,7 @@ class Env(object):
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-            if stub:
+            if stub or self.rehearse:
                 dist.init_process_group(backend="gloo")
             else:
                 dist.init_process_group(backend="nccl", device_id=self.dev)
@@ -542,7 +548,7 @@ def launch_ranks(n, argv, stub):
     """`--gpus n` without a launcher: start the n ranks as child processes (one per GPU, rendezvous on 127.0.0.1) BEFORE this process
     touches a GPU - it never does - relay rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and return
     the worst child exit code. A rank that fails takes the others down (they would wait in a collective)."""
-    if not stub and torch.cuda.device_count() < n:                    # (counting devices does not initialise the GPU)
+    if not stub and os.environ.get("PCV_BENCH_REHEARSE") != "1" and torch.cuda.device_count() < n:   # (counting devices does not initialise the GPU)
         print("bench.py: --gpus {} but {} HIP device(s) visible".format(n, torch.cuda.device_count()), file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -671,6 +677,8 @@ def main(argv=None):
         }
         if stub:
             out["stub"] = "launcher / collective self-test on CPU with gloo and a stand-in forward: NOT a measurement"
+        if env.rehearse:
+            out["rehearsal"] = "PCV_BENCH_REHEARSE=1: {} ranks share cuda:0, collectives through gloo: NOT a measurement".format(env.world)
         if profile:
             out["profile_mode"] = "PCV_BENCH_PROFILE=1: full-batch eager forwards only (for rocprofv3); value is not the benchmark figure"
         print(json.dumps(out), flush=True)

@@ -122,3 +122,26 @@ def test_c_abi_rccl_helpers_world_size_1(cuda_device):
         assert L.pcv_rccl_allgather(ctx, comm, None, ctypes.c_void_p(out.data_ptr()), 16, st) == -1
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def test_bench_two_ranks_share_this_gpu_end_to_end(cuda_device):
+    """`python bench.py --gpus 2` as the driver's multi-GPU tier runs it - a plain process that starts its own ranks - with the REAL
+    product path in both ranks (PCV_BENCH_REHEARSE=1: both on cuda:0, the collectives through gloo, because a test box has one GPU):
+    rank 0 loads the weights, rank 1 keeps its random init and must receive the packed arenas; the replica check (exit 5) and the
+    row-by-row parity check (exit 3) are live. One JSON line, `n_gpus` 2, marked as a rehearsal. Three processes on the card."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(PCV_BENCH_REHEARSE="1", PYTHONPATH=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "resnet18_bs256", "--batch", "32",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "rehearsal" in out
+    wb = out["weights_broadcast"]
+    assert wb and wb["messages"] >= 1 and wb["bytes"] > 1e6 and wb["replicas_agree"] is True
