@@ -249,3 +249,50 @@ def test_graph_batch_lanes_equal_single_lane(model, lanes, cuda_device):
     assert y_lanes.shape == y_eager.shape
     assert torch.equal(y_lanes, y_eager)
     assert torch.equal(y_again, torch.flip(y_eager, dims=[0]))
+
+
+@pytest.mark.parametrize("model", ["resnet18", "mobilenetv2_w1", "seresnet50", "efficientnet_b0"])
+def test_steps_in_flight_equal_eager(model, cuda_device):
+    """PipelinedNet: consecutive batches in flight on alternating streams (two or three captured forwards with their own static
+    buffers). DIFFERENT inputs on consecutive steps - so a slot that read another slot's buffers, or a step that started before its
+    input had landed, shows - and every step's logits equal the eager forward of ITS input bit for bit; the `then` callback runs on
+    the slot's stream behind the replay; a slot's output stays valid until that slot runs again."""
+    from pytorchcv_amd.graph import PipelinedNet
+    net = _net(model, "auto", cuda_device)
+    xs = [util.synth_input(6, seed=40 + i).to(cuda_device) for i in range(7)]
+    with torch.no_grad():
+        want = [net(x).clone() for x in xs]
+        for depth, lanes in ((2, 1), (3, 2)):
+            p = PipelinedNet(net, xs[0], depth=depth, lanes=lanes)
+            assert (p.depth, p.lanes) == (depth, lanes) and len(p.static_inputs) == depth
+            got = [p(x, then=lambda y: y.clone()) for x in xs]       # the clone rides on the slot's stream
+            p.synchronize()
+            for i, (g, w) in enumerate(zip(got, want)):
+                assert torch.equal(g, w), "step {} (slot {}) of depth {} differs from eager".format(i, i % depth, depth)
+            # x = None: the slot replays what its static input holds - the caller fills the buffers in place
+            for k, buf in enumerate(p.static_inputs):
+                buf.copy_(xs[k + 1])
+            torch.cuda.synchronize()
+            first = p.next_slot                                      # the slots run in turn, continuing where the loop above stopped
+            ys = [p(None) for _ in range(depth)]
+            p.synchronize()
+            for j in range(depth):
+                assert torch.equal(ys[j], want[(first + j) % depth + 1])
+
+
+def test_capture_best_picks_a_launcher_and_keeps_the_arithmetic(cuda_device):
+    """capture_best: below batch 64 one graph with one lane; from 64 up whichever of {one graph x two lanes, two graphs in flight}
+    replays faster on this device - either way the logits of a replay are the eager logits."""
+    from pytorchcv_amd.graph import capture_best, GraphedNet, PipelinedNet
+    net = _net("resnet18", "auto", cuda_device)
+    with torch.no_grad():
+        small = util.synth_input(8, seed=3).to(cuda_device)
+        g = capture_best(net, small)
+        assert isinstance(g, GraphedNet) and g.lanes == 1
+        assert torch.equal(g(small, clone=True), net(small))
+        big = util.synth_input(8, seed=4).to(cuda_device).repeat(8, 1, 1, 1).contiguous()
+        b = capture_best(net, big, steps=6)
+        assert isinstance(b, (GraphedNet, PipelinedNet))
+        y = b(None)
+        torch.cuda.synchronize()
+        assert torch.equal(y, net(big))

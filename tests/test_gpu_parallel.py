@@ -136,12 +136,13 @@ def test_bench_two_ranks_share_this_gpu_end_to_end(cuda_device):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env.update(PCV_BENCH_REHEARSE="1", PYTHONPATH=root)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "resnet18_bs256", "--batch", "32",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--inflight", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "rehearsal" in out
+    assert out["config"]["launch"].startswith("2 hipGraphs in flight")      # the all-gather of every step rides on its slot's stream
     wb = out["weights_broadcast"]
     assert wb and wb["messages"] >= 1 and wb["bytes"] > 1e6 and wb["replicas_agree"] is True
