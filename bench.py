@@ -496,6 +496,7 @@ def run_workload(env, workload, args, steps, warmup, profile=False):
                dtype=dtype, per_gpu_batch=batch,
                launch=(("{} hipGraphs in flight on alternating streams (consecutive steps overlap), {} batch lane(s) each".format(fwd.depth, fwd.lanes)
                         if pipelined else "hipGraph replay, {} batch lane(s) as parallel branches".format(fwd.lanes)) if use_graph else "eager"),
+               launchers_timed=getattr(fwd, "tuning", None),
                weights_broadcast=(dict(messages=bcast[0], bytes=bcast[1], replicas_agree=True,
                                        what="packed inference state (RCCL broadcast from rank 0), then every rank's logits of a common "
                                             "input compared (all-reduce MIN / MAX)") if bcast else None))
@@ -690,7 +691,7 @@ def main(argv=None):
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
             "config": {"workload": args.workload, "per_gpu_batch": res["per_gpu_batch"], "global_batch": env.world * res["per_gpu_batch"],
                        "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(env.world),
-                       "launch": res["launch"]},
+                       "launch": res["launch"], "launchers_timed_at_capture_img_per_s": res.get("launchers_timed")},
             "roofline": roof,
             "cpu_baseline": cpu,
             "weights_broadcast": res["weights_broadcast"],
