@@ -24,7 +24,7 @@ net = pytorchcv_amd.set_compute_dtype(net.to(dev), dtype)
 x = synth_input(8, seed=0).to(dev).repeat((batch + 7) // 8, 1, 1, 1)[:batch].contiguous()
 
 
-def run(depth, lanes, steps=40, warmup=6):
+def run(depth, lanes, steps=40, warmup=6, offset_ms=0.0):
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     graphs = []
     for s in streams:
@@ -39,6 +39,9 @@ def run(depth, lanes, steps=40, warmup=6):
                 outs[k] = graphs[k](graphs[k].static_in)
     loop(warmup)
     torch.cuda.synchronize()
+    if offset_ms > 0 and depth > 1:                                  # hold the second stream back once: a deliberate phase offset
+        with torch.cuda.stream(streams[1]):
+            torch.cuda._sleep(int(offset_ms * 1e-3 * 100e6))         # _sleep counts the 100 MHz wall clock of the device
     t0 = time.perf_counter()
     loop(steps)
     torch.cuda.synchronize()
@@ -50,3 +53,7 @@ def run(depth, lanes, steps=40, warmup=6):
 for depth, lanes in ((1, 2), (2, 1), (2, 2), (3, 1), (3, 2)):
     v, ms, same = run(depth, lanes)
     print("%s bs%d %s: %d graph(s) in flight x %d lane(s): %9.1f img/s  %.3f ms/step  outputs equal: %s" % (name, batch, dtype, depth, lanes, v, ms, same), flush=True)
+v0, ms0, _ = run(2, 1)
+for frac in (0.25, 0.5, 0.75):
+    v, ms, same = run(2, 1, offset_ms=frac * ms0)
+    print("%s bs%d %s: 2 in flight x 1 lane, second stream held back %.2f of a step once: %9.1f img/s  %.3f ms/step (no hold: %.1f)" % (name, batch, dtype, frac, v, ms, v0), flush=True)
