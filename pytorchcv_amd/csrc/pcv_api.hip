@@ -11,6 +11,7 @@
 #include "pcv_common.hpp"
 #include "igemm_inst.hpp"
 #include "d3q_inst.hpp"
+#include "d3w_inst.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
@@ -36,6 +37,8 @@ D3Q_SHAPES(D3Q_DECLARE, PCV_BF16)
 D3Q_SHAPES(D3Q_DECLARE, PCV_F16)
 D3Q1_SHAPES(D3Q1_DECLARE, PCV_BF16)
 D3Q1_SHAPES(D3Q1_DECLARE, PCV_F16)
+D3W_SHAPES(D3W_DECLARE, PCV_BF16)
+D3W_SHAPES(D3W_DECLARE, PCV_F16)
 
 struct pcv_ctx {
     int device = 0;
@@ -52,6 +55,7 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
+    int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
     int dw_flags = 0;           // tuning: bit 0 = non-temporal stores in the depthwise kernels
     int dw_th = 0;              // tuning: rows per thread of the depthwise kernel (0 = automatic)
@@ -426,7 +430,17 @@ static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
       reinterpret_cast<const void*>(d3q_kernel<PCV_F16, WC, WP, CBW, PBW, KS, true>)}},
 static const D3Shape kD1[] = {D3Q1_SHAPES(D3Q1_ROW, 0)};
 static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
+// the large-tile kernel (d3w_conv.hpp): eight self-loading waves, 512 threads
+#define D3W_ROW(DT, WC, WP, CBW, PBW)                                                                   \
+    {D3WCfg<WC, WP, CBW, PBW>::BM, D3WCfg<WC, WP, CBW, PBW>::BP, D3WCfg<WC, WP, CBW, PBW>::LDS,          \
+     {reinterpret_cast<const void*>(d3w_kernel<PCV_BF16, WC, WP, CBW, PBW>),                            \
+      reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW>)}},
+static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0)};
+static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static int enable_d3x3(pcv_ctx* ctx) {
+    for (int i = 0; i < kD3WCount; ++i)
+        for (int t = 0; t < 2; ++t)
+            HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
@@ -457,6 +471,17 @@ static int pick_d3x3(long long M, int Cout, int nk, long long slots) {
     auto tiles = [&](int i) { return ((Cout + kD3[i].BM - 1) / kD3[i].BM) * ((M + kD3[i].BP - 1) / kD3[i].BP); };
     if (tiles(wide) * 2 >= slots) return wide;
     if (tiles(narrow) * 4 >= slots) return narrow;
+    return -1;
+}
+// Large-tile kernel: the largest tile whose tile count still fills at least three quarters of one round of CUs (d3w_inst.hpp order:
+// 0 = 256 x 224, 1 = 128 x 416, 2 = 128 x 384, 3 = 128 x 224, 4 = 64 x 448); -1 = leave the layer to d3q_kernel / the generic kernel.
+static int pick_d3w(long long M, int Cout, long long slots) {
+    auto tiles = [&](int i) { return (long long)((Cout + kD3W[i].BM - 1) / kD3W[i].BM) * ((M + kD3W[i].BP - 1) / kD3W[i].BP); };
+    static const int c256[] = {0, 1, 3}, c128[] = {1, 3}, c64[] = {4};
+    const int* cand = Cout % 256 == 0 ? c256 : (Cout > 64 ? c128 : c64);
+    const int n = Cout % 256 == 0 ? 3 : (Cout > 64 ? 2 : 1);
+    for (int i = 0; i < n; ++i)
+        if (tiles(cand[i]) * 4 >= slots * 3) return cand[i];
     return -1;
 }
 
@@ -783,6 +808,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "wpair") g_wpair_mask = value;            // process-wide: the `supported` query has no context argument
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
+    else if (k == "d3w") ctx->use_d3w = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "stem32") ctx->use_stem32 = value;
     else if (k == "d1x1") ctx->use_d1x1 = value;
@@ -1072,6 +1098,7 @@ enum ConvKernel {
     CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
+    CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
     CK_D3Q,         // d3q_conv.hpp: dense 3x3 / s1 / p1, 16 bit
     CK_D3Q_1X1,     // d3q_conv.hpp in its 1x1 mode: K-heavy pointwise layers
     CK_HEAD,        // head_gemm.hpp: fp32 dense layer on a 1x1 map (classifier)
@@ -1148,6 +1175,11 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
     if (P.conv3 && !A.gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && clamp_acts && A.scale && A.shift &&
         G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull &&
         G.xbytes + 2ull * (unsigned long long)d->W * d->Cin * 2ull < 0x80000000ull) {
+        if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
+            R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
+                                       : pick_d3w((long long)G.M64, d->Cout, (long long)block_slots(ctx, 1));
+            if (R.shape >= 0) { R.kernel = CK_D3W; return R; }
+        }
         R.shape = ctx->use_d3x3 > 0 ? std::min(ctx->use_d3x3 - 1, kD3Count - 1)
                                     : pick_d3x3((long long)G.M64, d->Cout, P.nk, (long long)ctx->num_cu);
         if (R.shape >= 0) { R.kernel = CK_D3Q; return R; }
@@ -1272,14 +1304,15 @@ static int launch_gconv_flat(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPla
 
 // d3q_kernel, both modes: `one` = the 1x1 mode (kD1 shapes; H / W / HW describe the OUTPUT map, a strided 1x1 reads every
 // stride-th pixel), else the dense 3x3 mode (kD3 shapes)
-static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, int shape, bool one) {
+static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, int shape, bool one,
+                      bool wide = false) {
     const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
     const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * 2ull;
     if (ypitch < d->Cout || (ypitch * 2) % 16 != 0)
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
     if (ybytes >= 0x80000000ull)
         return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
-    const D3Shape& S = one ? kD1[shape] : kD3[shape];
+    const D3Shape& S = wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape]);       // wide: d3w_kernel (512 threads), same parameter block
     D3Params q;
     std::memset(&q, 0, sizeof(q));
     q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
@@ -1310,7 +1343,7 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     long long nb = slots < nT ? slots : nT;
     nb = (nb + 7) / 8 * 8;
     void* args[] = {&q};
-    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(768), args, (size_t)S.lds, A.stream));
+    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(wide ? 512 : 768), args, (size_t)S.lds, A.stream));
     return PCV_OK;
 }
 
@@ -1448,6 +1481,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         case CK_STEM: return launch_stem(ctx, d, P, G, A);
         case CK_GCONV_ROWS: return launch_gconv_rows(ctx, d, P, G, A, R.rows);
         case CK_GCONV_FLAT: return launch_gconv_flat(ctx, d, P, G, A);
+        case CK_D3W: return launch_d3q(ctx, d, P, G, A, R.shape, false, true);
         case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
         case CK_D3Q_1X1: return launch_d3q(ctx, d, P, G, A, R.shape, true);
         case CK_HEAD: return launch_head(ctx, d, P, G, A);

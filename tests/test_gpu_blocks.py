@@ -133,7 +133,8 @@ _CONV3_SHAPES = [
 
 
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(8)])
+@pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(8)] +
+                         ["d3w:auto"] + ["d3w:{}".format(i) for i in range(5)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
 def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device):
@@ -142,8 +143,11 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device
     from pytorchcv_amd.models.common.conv import conv3x3_block
     from oracle import refnet
     if kernel != "generic" and dtype == "fp32":
-        pytest.skip("the 8-wave dense 3x3 kernel is 16-bit only; fp32 takes the generic implicit GEMM")
-    d3 = 0 if kernel == "generic" else (-1 if kernel.endswith("auto") else int(kernel.split(":")[1]) + 1)    # forced tile shape
+        pytest.skip("the dedicated dense 3x3 kernels are 16-bit only; fp32 takes the generic implicit GEMM")
+    # forced kernel / tile shape: "d3x3" = the 8 + 4-wave kernel (d3q_conv.hpp), "d3w" = the large-tile kernel (d3w_conv.hpp)
+    shape_no = -1 if kernel.endswith("auto") else (int(kernel.split(":")[1]) + 1 if ":" in kernel else 0)
+    d3 = 0 if kernel == "generic" else (shape_no if kernel.startswith("d3x3") else -1)
+    dw = shape_no if kernel.startswith("d3w") else 0
     N, C, Cout, H, W, use_res = shape
     blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
     sd = util.synth_state_dict(blk.state_dict(), seed=77)
@@ -154,7 +158,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device
     with torch.no_grad():
         xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
         rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
-        with util.tuning(max_blocks=grid, d3x3=d3):
+        with util.tuning(max_blocks=grid, d3x3=d3, d3w=dw):
             yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
         if kernel != "generic":
             # same K order, same MFMA sequence per accumulator, same epilogue arithmetic: bit-identical to the generic kernel
