@@ -1,14 +1,13 @@
 // d3w_inst.hpp - the instantiations of d3w_kernel (d3w_bf16.hip / d3w_f16.hip define them, pcv_api.hip sees `extern template`).
-//   X(DT, WC, WP, CBW, PBW): block tile = (16 CBW WC) channels x (16 PBW WP) pixels, eight self-loading waves
+//   X(DT, WC, WP, CBW, PBW, KS, NSA): block tile = (16 CBW WC) channels x (16 PBW WP) pixels, eight self-loading waves, KS K-halves per interval, NSA weight-ring slots
 #pragma once
 #include "d3w_conv.hpp"
 
 #define D3W_SHAPES(X, DT)      \
-    X(DT, 4, 2, 4, 7)          /* 0: 256 ch x 224 px, wave 64 x 112 */  \
-    X(DT, 4, 2, 2, 13)         /* 1: 128 x 416, wave 32 x 208 */        \
-    X(DT, 2, 4, 4, 6)          /* 2: 128 x 384, wave 64 x 96 */         \
-    X(DT, 4, 2, 2, 7)          /* 3: 128 x 224, wave 32 x 112 */        \
-    X(DT, 2, 4, 2, 7)          /* 4: 64 x 448, wave 32 x 112 */
+    X(DT, 4, 2, 4, 7, 1, 3)     /* 0: 256 ch x 224 px, wave 64 x 112, K-half intervals */      \
+    X(DT, 4, 2, 4, 7, 2, 3)     /* 1: 256 x 224, whole K-steps per interval */                 \
+    X(DT, 2, 4, 4, 7, 1, 2)     /* 2: 128 x 448, wave 64 x 112, two-slot weight ring */        \
+    X(DT, 2, 4, 2, 7, 2, 3)     /* 3: 64 x 448, wave 32 x 112, whole K-steps per interval */
 
-#define D3W_DEFINE(DT, WC, WP, CBW, PBW) template __global__ void d3w_kernel<DT, WC, WP, CBW, PBW>(const D3Params);
-#define D3W_DECLARE(DT, WC, WP, CBW, PBW) extern template __global__ void d3w_kernel<DT, WC, WP, CBW, PBW>(const D3Params);
+#define D3W_DEFINE(DT, WC, WP, CBW, PBW, KS, NSA) template __global__ void d3w_kernel<DT, WC, WP, CBW, PBW, KS, NSA>(const D3Params);
+#define D3W_DECLARE(DT, WC, WP, CBW, PBW, KS, NSA) extern template __global__ void d3w_kernel<DT, WC, WP, CBW, PBW, KS, NSA>(const D3Params);

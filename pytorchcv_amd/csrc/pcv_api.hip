@@ -431,16 +431,17 @@ static const int kD3Count = (int)(sizeof(kD3) / sizeof(kD3[0]));
 static const D3Shape kD1[] = {D3Q1_SHAPES(D3Q1_ROW, 0)};
 static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 // the large-tile kernel (d3w_conv.hpp): eight self-loading waves, 512 threads
-#define D3W_ROW(DT, WC, WP, CBW, PBW)                                                                   \
-    {D3WCfg<WC, WP, CBW, PBW>::BM, D3WCfg<WC, WP, CBW, PBW>::BP, D3WCfg<WC, WP, CBW, PBW>::LDS,          \
-     {reinterpret_cast<const void*>(d3w_kernel<PCV_BF16, WC, WP, CBW, PBW>),                            \
-      reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW>)}},
+#define D3W_ROW(DT, WC, WP, CBW, PBW, KS, NSA)                                                                                   \
+    {D3WCfg<WC, WP, CBW, PBW, KS, NSA>::BM, D3WCfg<WC, WP, CBW, PBW, KS, NSA>::BP, D3WCfg<WC, WP, CBW, PBW, KS, NSA>::LDS,       \
+     {reinterpret_cast<const void*>(d3w_kernel<PCV_BF16, WC, WP, CBW, PBW, KS, NSA>),                                           \
+      reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW, KS, NSA>)}},
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
+
     for (int i = 0; i < kD3Count; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3[i].lds));
@@ -473,16 +474,15 @@ static int pick_d3x3(long long M, int Cout, int nk, long long slots) {
     if (tiles(narrow) * 4 >= slots) return narrow;
     return -1;
 }
-// Large-tile kernel: the largest tile whose tile count still fills at least three quarters of one round of CUs (d3w_inst.hpp order:
-// 0 = 256 x 224, 1 = 128 x 416, 2 = 128 x 384, 3 = 128 x 224, 4 = 64 x 448); -1 = leave the layer to d3q_kernel / the generic kernel.
+// Large-tile kernel (d3w_inst.hpp order: 0 / 1 = 256 x 224, 2 = 128 x 448, 3 = 64 x 448): layers whose output channels fill 256- or
+// 128-row tiles and whose tile count fills at least three quarters of one round of CUs; -1 = leave the layer to d3q_kernel / the generic
+// kernel. Measured at batch 256 (us, d3q -> this kernel): 256 ch @14x14 64.7 -> 55.3 (whole K-steps per interval; K-half intervals 57.1),
+// 128 ch @28x28 70.4 -> 64.1; 64 ch @56x56 83.4 -> 84.9 and 512 ch @7x7 67.5 -> 73.5 (224 tiles of 128 x 224) stay on d3q.
 static int pick_d3w(long long M, int Cout, long long slots) {
-    auto tiles = [&](int i) { return (long long)((Cout + kD3W[i].BM - 1) / kD3W[i].BM) * ((M + kD3W[i].BP - 1) / kD3W[i].BP); };
-    static const int c256[] = {0, 1, 3}, c128[] = {1, 3}, c64[] = {4};
-    const int* cand = Cout % 256 == 0 ? c256 : (Cout > 64 ? c128 : c64);
-    const int n = Cout % 256 == 0 ? 3 : (Cout > 64 ? 2 : 1);
-    for (int i = 0; i < n; ++i)
-        if (tiles(cand[i]) * 4 >= slots * 3) return cand[i];
-    return -1;
+    const int shape = Cout % 256 == 0 ? 1 : (Cout % 128 == 0 ? 2 : -1);
+    if (shape < 0) return -1;
+    const long long tiles = (long long)(Cout / kD3W[shape].BM) * ((M + kD3W[shape].BP - 1) / kD3W[shape].BP);
+    return tiles * 4 >= slots * 3 ? shape : -1;
 }
 
 // ---- stem kernel ------------------------------------------------------------------------------------------------------
