@@ -60,6 +60,8 @@ CLASS_BOUND = {"dense3x3": "mfma", "dense1x1_kheavy": "mfma"}           # everyt
 def kernel_class_of(name: str):
     """Kernel class of a rocprofv3 kernel name, None for kernels outside the convolution path (pools, head, layout, torch)."""
     head = name.split("(")[0].rstrip()
+    if "d3w_kernel" in name:
+        return "dense3x3"
     if "d3q_kernel" in name:
         return "dense1x1_kheavy" if head.endswith("true>") else "dense3x3"
     if "igemm_conv_kernel" in name:
@@ -301,12 +303,14 @@ def cpu_baseline(model, sd_cpu, budget_s=12.0):
 
 def committed_profile(workload, dtype):
     """{class: dict(calls, avg_us)} over ALL launches of the committed rocprofv3 --kernel-trace --stats summary of this workload
-    (profiles/r03_<workload>_<dtype>_kernel_stats.csv: collected with PCV_BENCH_PROFILE=1, where bench.py runs nothing but
-    full-batch forwards - every dispatch in the table is a full-batch launch), and the file; ({}, None) when there is none."""
+    (profiles/r<NN>_<workload>_<dtype>_kernel_stats.csv, the newest round present: collected with PCV_BENCH_PROFILE=1, where bench.py
+    runs nothing but full-batch forwards - every dispatch in the table is a full-batch launch), and the file; ({}, None) when there is none."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r03_{}_{}_kernel_stats.csv".format(workload, dtype))
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_{}_{}_kernel_stats.csv".format(workload, dtype))))
+    if not found:
         return {}, None
+    path = found[-1]
     acc = {}
     with open(path) as f:
         for row in csv.DictReader(f):
@@ -398,6 +402,10 @@ def run_workload(env, workload, args, steps, warmup, profile=False):
     model, batch, klass = WORKLOADS[workload]
     if args.batch > 0:
         batch = args.batch
+    if args.scaling == "strong":                       # BASELINE config 5 literally: a fixed global batch split over the ranks
+        if args.global_batch % env.world != 0:
+            env.fail(2, "--global-batch {} does not split over {} rank(s)".format(args.global_batch, env.world))
+        batch = args.global_batch // env.world
     rank, dev = env.rank, env.dev
     sd_cpu = None
     if env.stub:
@@ -425,7 +433,13 @@ def run_workload(env, workload, args, steps, warmup, profile=False):
     if env.use_dist:
         # RCCL broadcast of rank 0's PACKED inference state over xGMI (16-bit arenas + fp32 scale/shift: half the fp32 state;
         # the receiving ranks do not re-pack)
+        env.sync()
+        dist.barrier()
+        tb = time.perf_counter()
         bcast = broadcast_packed_state(net, src=0)
+        env.sync()
+        dist.barrier()
+        bcast_s = time.perf_counter() - tb
         with torch.no_grad():
             if not replicas_agree(net(common)):      # a tensor the broadcast missed = plausible but different logits on ranks != 0
                 env.fail(5, "replicas disagree on a common input after the weight broadcast")
@@ -442,7 +456,11 @@ def run_workload(env, workload, args, steps, warmup, profile=False):
             # ~60 kernel launches replayed by one hipGraphLaunch; the inputs are static buffers resident in HBM. --inflight 0 (default):
             # the launcher that replays fastest HERE - one graph of two batch lanes, or two full-batch graphs in flight on alternating
             # streams (consecutive steps overlap: the single-round 7x7 tail of step n runs under the head of step n+1)
-            if args.inflight == 0 and args.lanes == 0:
+            if args.inflight == 0 and args.lanes == 0 and env.use_dist:
+                # multi-rank runs do not time launchers per rank (ranks could keep different ones and the MAX-reduced figure would
+                # be a mix): every rank replays the launcher that wins on 8 of the 9 workloads at N = 1
+                fwd = PipelinedNet(net, x, depth=2, lanes=1, own_input=True)
+            elif args.inflight == 0 and args.lanes == 0:
                 fwd = capture_best(net, x, own_input=True)
             elif args.inflight >= 2:
                 fwd = PipelinedNet(net, x, depth=args.inflight, lanes=max(1, args.lanes), own_input=True)
@@ -497,10 +515,42 @@ def run_workload(env, workload, args, steps, warmup, profile=False):
                launch=(("{} hipGraphs in flight on alternating streams (consecutive steps overlap), {} batch lane(s) each".format(fwd.depth, fwd.lanes)
                         if pipelined else "hipGraph replay, {} batch lane(s) as parallel branches".format(fwd.lanes)) if use_graph else "eager"),
                launchers_timed=getattr(fwd, "tuning", None),
-               weights_broadcast=(dict(messages=bcast[0], bytes=bcast[1], replicas_agree=True,
+               launcher_choice=("fixed for multi-rank runs (the same on every rank)" if env.use_dist and args.inflight == 0 and args.lanes == 0
+                                else ("timed at capture on this GPU" if args.inflight == 0 and args.lanes == 0 else "flags")),
+               weights_broadcast=(dict(messages=bcast[0], bytes=bcast[1], seconds=round(bcast_s, 4), replicas_agree=True,
                                        what="packed inference state (RCCL broadcast from rank 0), then every rank's logits of a common "
                                             "input compared (all-reduce MIN / MAX)") if bcast else None))
     return res, dict(net=net, x=x, sd_cpu=sd_cpu, model=model, klass=klass, dtype=dtype, batch=batch)
+
+
+def forward_latency(ctx, samples=24):
+    """SURVEY 8d's latency figure: HIP events around ONE forward of the resident batch on ONE stream (a single-lane hipGraph replay:
+    nothing of another step overlaps it), `samples` replays one after the other, each synchronised before the next starts."""
+    from pytorchcv_amd.graph import capture
+    g = capture(ctx["net"], ctx["x"], own_input=True, lanes=1)
+    ms = []
+    for i in range(samples + 3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g(None)
+        e1.record()
+        e1.synchronize()
+        if i >= 3:
+            ms.append(e0.elapsed_time(e1))
+    del g
+    ms.sort()
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    return dict(latency_ms_median=round(med, 4), latency_ms_min=round(ms[0], 4), latency_ms_max=round(ms[-1], 4), samples=len(ms),
+                images_per_sec_at_median_latency=round(ctx["batch"] / med * 1e3, 1),
+                how="HIP events around one single-lane hipGraph replay of the whole forward on one stream, one at a time (SURVEY 8d)")
+
+
+def compact_roofline(roof):
+    """The north-star class of a workload, as it goes into `other_configs`."""
+    if roof is None:
+        return None
+    return {k: roof.get(k) for k in ("kernel_class", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                     "traffic", "rocprof_avg_launch_us", "rocprof_frac")}
 
 
 def roofline_of(env, workload, ctx, passes):
@@ -563,13 +613,38 @@ def roofline_of(env, workload, ctx, passes):
     return roof
 
 
+def visible_gpus():
+    """How many GPUs the ranks will see, WITHOUT touching the HIP / HSA runtime in this process (the launcher parent must stay
+    GPU-free: torch.cuda.device_count() can fall back to hipGetDeviceCount). An explicit visibility list wins; else the KFD topology
+    (a node with SIMDs is a GPU); None when neither says anything (the ranks then fail by themselves)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for ln in f:
+                    if ln.startswith("simd_count") and int(ln.split()[1]) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launch_ranks(n, argv, stub):
     """`--gpus n` without a launcher: start the n ranks as child processes (one per GPU, rendezvous on 127.0.0.1) BEFORE this process
-    touches a GPU - it never does - relay rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and return
+    touches a GPU - it never does (devices are counted from the environment / sysfs, `visible_gpus`) - relay rank 0's JSON line on stdout (everything else the ranks print goes to stderr) and return
     the worst child exit code. A rank that fails takes the others down (they would wait in a collective)."""
-    if not stub and os.environ.get("PCV_BENCH_REHEARSE") != "1" and torch.cuda.device_count() < n:   # (counting devices does not initialise the GPU)
-        print("bench.py: --gpus {} but {} HIP device(s) visible".format(n, torch.cuda.device_count()), file=sys.stderr)
-        return 2
+    if not stub and os.environ.get("PCV_BENCH_REHEARSE") != "1":
+        have = visible_gpus()                                         # from the environment / sysfs: no HIP or HSA call in this process
+        if have is not None and have < n:
+            print("bench.py: --gpus {} but {} GPU(s) visible".format(n, have), file=sys.stderr)
+            return 2
+    limit = float(os.environ.get("PCV_BENCH_TIMEOUT_S", "1500"))     # a rank stuck in RCCL init or a collective must not hang the caller
+    t_start = time.time()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -586,6 +661,14 @@ def launch_ranks(n, argv, stub):
     try:
         pending = set(range(n))
         while pending:
+            if time.time() - t_start > limit:
+                print("bench.py: ranks {} still running after {:.0f} s (PCV_BENCH_TIMEOUT_S): terminating them".format(sorted(pending), limit),
+                      file=sys.stderr)
+                for o in pending:
+                    killed.add(o)
+                    procs[o].terminate()
+                worst = worst or 124
+                limit = float("inf")
             for r in sorted(pending):
                 rc = procs[r].poll()
                 if rc is None:
@@ -637,6 +720,9 @@ def main(argv=None):
     ap.add_argument("--lanes", type=int, default=0, help="independent batch slices captured as parallel graph branches, so that "
                                                         "one slice's tile-schedule tails are filled by the other's kernels "
                                                         "(0: pytorchcv_amd.graph.auto_lanes, i.e. 2 from batch 64 up)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch per GPU (default); strong: --global-batch images split over the ranks (BASELINE config 5: 2048)")
+    ap.add_argument("--global-batch", type=int, default=2048)
     args = ap.parse_args(argv)
     stub = os.environ.get("PCV_BENCH_STUB") == "1"
     # PCV_BENCH_PROFILE=1 (the rocprofv3 / PMC collection runs): nothing but full-batch eager forwards on one lane - no 8-image
@@ -652,8 +738,11 @@ def main(argv=None):
               file=sys.stderr)
     if stub and os.environ.get("PCV_BENCH_STUB_FAIL_RANK") == str(env.rank):
         env.fail(7, "rank {} fails on request (launcher self-test)".format(env.rank))
+    if stub and os.environ.get("PCV_BENCH_STUB_HANG_RANK") == str(env.rank):
+        time.sleep(3600)                               # (launcher self-test: a rank that never returns)
+    tune_overrides = [kv for kv in os.environ.get("PCV_BENCH_TUNE", "").split(",") if kv]
     if not stub:
-        for kv in filter(None, os.environ.get("PCV_BENCH_TUNE", "").split(",")):       # dev only: "key=value,..." -> pcv_set_tuning
+        for kv in tune_overrides:                    # dev only: "key=value,..." -> pcv_set_tuning; reported in the JSON line
             from pytorchcv_amd import _lib
             k, v = kv.split("=")
             _lib.check(_lib.lib().pcv_set_tuning(_lib.ctx_for(env.local_rank), k.encode(), int(v)), _lib.ctx_for(env.local_rank))
@@ -661,6 +750,7 @@ def main(argv=None):
     res, ctx = run_workload(env, args.workload, args, args.steps, args.warmup, profile=profile)
     rank0_extras = env.rank == 0 and not stub and not profile
     roof = roofline_of(env, args.workload, ctx, max(3, min(args.steps, 10))) if rank0_extras else None
+    lat = forward_latency(ctx) if (rank0_extras and args.graph != 0) else None
     cpu = cpu_baseline(ctx["model"], ctx["sd_cpu"]) if (rank0_extras and env.world == 1 and not args.no_cpu_baseline) else None
     others = None
     if rank0_extras and env.world == 1 and not args.no_other_configs and args.workload == "resnet50_bs256" and args.batch == 0:
@@ -670,7 +760,8 @@ def main(argv=None):
         for w in OTHER_CONFIGS:
             r, c = run_workload(env, w, args, 10, 3)
             others[w] = dict(value=r["value"], unit="images/sec", ms_per_step=r["ms_per_step"], steps=10, warmup=3, dtype=r["dtype"],
-                             launch=r["launch"], rows_checked="every row of the timed batch equals the 8-image eager forward bit for bit")
+                             launch=r["launch"], rows_checked="every row of the timed batch equals the 8-image eager forward bit for bit",
+                             roofline=compact_roofline(roofline_of(env, w, c, 3)), latency=forward_latency(c, samples=20))
             del r, c
             torch.cuda.empty_cache()
 
@@ -678,6 +769,8 @@ def main(argv=None):
         model, _, _ = WORKLOADS[args.workload]
         out = {
             "metric": "images/sec @224x224 ({} bs={}/GPU)".format(model, res["per_gpu_batch"]),
+            "value_is": "steady-state throughput: images of the K timed steps / their wall time ({}); the one-forward latency figure of "
+                        "SURVEY 8d is `latency`".format(res["launch"]),
             "value": res["value"],
             "unit": "images/sec",
             "n_gpus": env.world,
@@ -685,14 +778,17 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": res["dtype"],
             "data": "synthetic (seeded N(0,1) images, seeded calibrated random-init weights of the named architecture)",
             "config": {"workload": args.workload, "per_gpu_batch": res["per_gpu_batch"], "global_batch": env.world * res["per_gpu_batch"],
                        "input": "fp32 NCHW 224x224 resident in HBM", "parallelism": "batch-sharded replicas x{}".format(env.world),
-                       "launch": res["launch"], "launchers_timed_at_capture_img_per_s": res.get("launchers_timed")},
+                       "launch": res["launch"], "launcher_choice": res.get("launcher_choice"),
+                       "launchers_timed_at_capture_img_per_s": res.get("launchers_timed"),
+                       "tuning_overrides": tune_overrides or None},
             "roofline": roof,
+            "latency": lat,
             "cpu_baseline": cpu,
             "weights_broadcast": res["weights_broadcast"],
             "other_configs": others,

@@ -75,6 +75,13 @@ struct D3Params {
 // rotates the section from K-step to K-step (steps 4..30: every section three times). Stamp points sit behind a barrier or an
 // explicit lgkmcnt(0), where no LDS read is outstanding (s_memtime returns through lgkmcnt). The product build compiles none
 // of this.
+// Timing experiments that produce WRONG results (pcv_set_tuning("dbg", bits)) exist only in diagnostic builds (make EXTRA=-DPCV_DBG_FLAGS);
+// the product library compiles none of them and refuses the key.
+#ifdef PCV_DBG_FLAGS
+#define D3_DBG(bits) ((p.dbgflags & (bits)) != 0)
+#else
+#define D3_DBG(bits) false
+#endif
 #ifdef D3X3_STAMPS
 #define D3_STAMP(slot)                                                                                     \
     do {                                                                                                   \
@@ -257,7 +264,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
         if constexpr (PH == 1) { if (prep_c == 2) { table_rows(prep_t, T2{}, T3{}, pbvN, vmaskN); prep_c = 3; } }
     };
     auto next_table = [&](int t) __attribute__((always_inline)) {   // tile t becomes the loaders' current tile
-        if (prep_t == t && prep_c == 3 && !(p.dbgflags & 16)) {
+        if (prep_t == t && prep_c == 3 && !D3_DBG(16)) {
 #pragma unroll
             for (int j = 0; j < XLW; ++j) pbv[j] = pbvN[j];
             vmask[0] = vmaskN[0];
@@ -287,7 +294,7 @@ __device__ __forceinline__ void d3q_loader(const D3Params& p, char* smem, const 
             if (ONE || ++lb_r == 3) {
                 lb_r = 0;
                 lb_tile += T.tstride;
-                if (lb_tile < T.tend && !(p.dbgflags & 4)) next_table(lb_tile);
+                if (lb_tile < T.tend && !D3_DBG(4)) next_table(lb_tile);
             }
         }
     };
@@ -493,7 +500,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
         }
     };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
-        if (p.dbgflags & 2) return;
+        if (D3_DBG(2)) return;
         const int chTile = t % p.nChTiles;
         const int tileP0 = (t / p.nChTiles) * BP;
         const int mBase = tileP0 + wp * 16 * PBW + fr;
@@ -536,7 +543,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-                const bool ok = chok && m < p.M && !(p.dbgflags & 1);
+                const bool ok = chok && m < p.M && !D3_DBG(1);
                 const uint32_t boff = ok ? (uint32_t)(((size_t)m * p.Ypitch + ch0) * 2) : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
             }
@@ -567,7 +574,7 @@ __device__ __forceinline__ void d3q_body(const D3Params& p, char* smem, const in
                 epilogue(ep_tile);
                 zero_acc();
                 if constexpr (!ONE) {
-                    if (!(p.dbgflags & 8)) {
+                    if (!D3_DBG(8)) {
                         hm0 = hmN & 0xFFFFu;
                         hm2 = hmN >> 16;
                     }

@@ -218,7 +218,7 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
     // behind the wave's first row)
     auto reads = [&](auto Uc, int sa, int sb, auto Qc, int h) __attribute__((always_inline)) {
         constexpr int Q = decltype(Qc)::value, U = decltype(Uc)::value;
-#ifdef D3W_CYCLES
+#if defined(D3W_CYCLES) && defined(PCV_DBG_FLAGS)
         if (p.dbgflags & 128) return;                            // (bit 128: no fragment reads)
 #endif
         const uint32_t abase = afrag + (uint32_t)(sa * G::ASZ);
@@ -242,7 +242,7 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
         }
     };
     auto mfmas = [&]() __attribute__((always_inline)) {
-#ifdef D3W_CYCLES
+#if defined(D3W_CYCLES) && defined(PCV_DBG_FLAGS)
         if (p.dbgflags & 256) return;                            // (bit 256: no MFMAs)
 #endif
         __builtin_amdgcn_s_setprio(1);
@@ -392,7 +392,7 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
             }
             if (s == K_total) return true;
         }
-#ifdef D3W_CYCLES      // subtract-a-component timing (results wrong): dbg bit 32 = no activation pieces, 64 = no weight pieces in the loop
+#if defined(D3W_CYCLES) && defined(PCV_DBG_FLAGS)      // subtract-a-component timing (results wrong): dbg bit 32 = no activation pieces, 64 = no weight pieces in the loop
         const bool moreA = s + AHEAD < K_total && !(p.dbgflags & 64), moreB = s - Q + 3 < K_total && !(p.dbgflags & 32);
 #else
         const bool moreA = s + AHEAD < K_total, moreB = s - Q + 3 < K_total;      // K-step s + AHEAD / group g + 1 exist

@@ -814,7 +814,14 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d1x1") ctx->use_d1x1 = value;
     else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
-    else if (k == "dbg") ctx->dbg_flags = value;
+    else if (k == "dbg") {
+#ifdef PCV_DBG_FLAGS
+        ctx->dbg_flags = value;
+#else
+        if (value != 0)
+            return fail(ctx, PCV_ERR_INVALID, "pcv_set_tuning: \"dbg\" (timing experiments that produce wrong results) needs a -DPCV_DBG_FLAGS build");
+#endif
+    }
     else if (k == "dw_th") ctx->dw_th = value;
     else if (k == "dw_flags") ctx->dw_flags = value;
     else if (k == "dbg_lo") ctx->dbg_ptr = (ctx->dbg_ptr & 0xFFFFFFFF00000000ull) | (unsigned)value;

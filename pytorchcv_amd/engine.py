@@ -39,6 +39,18 @@ def set_compute_dtype(net: nn.Module, dtype: str) -> nn.Module:
     return net
 
 
+def stamp_family_dtype(net: nn.Module) -> nn.Module:
+    """Give every sub-module of `net` the 16-bit mode its family declares (`pcv_16bit` on the net class), so that "auto" resolves to the
+    SAME type whether the whole net or one of its parts (`net.features(x)`, a unit, a block) is called with an NCHW tensor. Called at
+    the end of the family's constructor."""
+    mode = getattr(net, "pcv_16bit", None)
+    if mode is not None:
+        for m in net.modules():
+            if m is not net:
+                m.pcv_16bit = mode
+    return net
+
+
 def compute_dtype_of(module: nn.Module) -> str:
     """The type `module` runs in. "auto" resolves to the module's own 16-bit mode: bf16, except for the net classes that declare
     `pcv_16bit = "fp16"` - the depthwise-separable families (MobileNetV2 / V3, EfficientNet), whose logits stay within the
@@ -220,6 +232,8 @@ def boundary(module: nn.Module, x, fn, stem: bool = False):
     dtype = compute_dtype_of(module)
     guard = Fp16Guard(x.device, DTYPES[dtype][1])
     y = fn(from_nchw(x, dtype, stem=stem))
+    if isinstance(y, tuple):                          # (output, pre-activated input) of the pre-activation blocks: the guard poisons both
+        return tuple(guard.finish(to_nchw(v)) if isinstance(v, NHWC) else v for v in y)
     y = to_nchw(y) if isinstance(y, NHWC) else y
     return guard.finish(y) if torch.is_tensor(y) and y.dtype == torch.float32 else y
 

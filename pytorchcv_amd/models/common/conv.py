@@ -254,12 +254,7 @@ class PreConvBlock(nn.Module):
         return (y, pre) if self.return_preact else y
 
     def forward(self, x):
-        if isinstance(x, engine.NHWC):
-            return self._run(x)
-        out = self._run(engine.from_nchw(x, engine.compute_dtype_of(self)))
-        if self.return_preact:
-            return engine.to_nchw(out[0]), engine.to_nchw(out[1])
-        return engine.to_nchw(out)
+        return engine.boundary(self, x, self._run)      # (tensor entry: the module's resolved type + the fp16 range guard)
 
 
 def pre_conv1x1_block(stride=1, padding=0, **kwargs):

@@ -142,6 +142,7 @@ class EfficientNet(nn.Module):
             self.output.add_module("dropout", nn.Dropout(p=dropout_rate))      # identity at inference: never launched
         self.output.add_module("fc", LinearHead(in_features=in_channels, out_features=num_classes))
         init_conv_params(self)
+        engine.stamp_family_dtype(self)                    # sub-modules called on their own resolve "auto" like the net
 
     def _head(self, a):
         if self.training:

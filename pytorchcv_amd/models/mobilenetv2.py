@@ -53,6 +53,7 @@ class MobileNetV2(ClassifierNet):
                 remove_exp_conv=remove_exp_conv, activation=act))
         self.features.add_module("final_block", conv1x1_block(in_channels=width, out_channels=final_block_channels, activation=act))
         self.finish(final_block_channels, head=conv1x1(in_channels=final_block_channels, out_channels=num_classes, bias=False))
+        engine.stamp_family_dtype(self)                    # sub-modules called on their own resolve "auto" like the net
 
     def _head(self, a):
         if a.H != 1 or a.W != 1:

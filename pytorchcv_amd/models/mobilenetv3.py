@@ -115,6 +115,7 @@ class MobileNetV3(nn.Module):
         self.output = MobileNetV3Classifier(in_channels=in_channels, out_channels=num_classes,
                                             mid_channels=classifier_mid_channels, dropout_rate=0.2)
         init_conv_params(self)
+        engine.stamp_family_dtype(self)                    # sub-modules called on their own resolve "auto" like the net
 
     def _head(self, a):
         if a.H != 1 or a.W != 1:

@@ -69,10 +69,7 @@ def _run_body(body, x):
         blocks = body.chain()
         pre = blocks[0].preact(a)
         return _chain_forward(blocks, pre), pre
-    if isinstance(x, engine.NHWC):
-        return run(x)
-    y, pre = run(engine.from_nchw(x, engine.compute_dtype_of(body)))
-    return engine.to_nchw(y), engine.to_nchw(pre)
+    return engine.boundary(body, x, run)               # (tensor entry: the module's resolved type + the fp16 range guard)
 
 
 class PreResUnit(nn.Module):

@@ -264,3 +264,35 @@ def test_guard_api_argument_checks(cuda_device):
     assert L.pcv_fp16_guard_end(ctx, ctypes.c_void_p(slot.data_ptr()), ctypes.c_void_p(y.data_ptr()), 8, st) == 0
     torch.cuda.synchronize()
     assert bool((y == 0).all())
+
+
+@pytest.mark.gpu
+def test_submodule_called_with_a_tensor_runs_in_the_family_type_and_is_guarded(cuda_device):
+    """`net.features(x)` (any part of an fp16-family net called with an NCHW tensor) resolves "auto" like `net(x)` - the
+    result equals the explicit-fp16 handle path bit for bit - and the pre-activation blocks' tensor entry carries the range guard."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.model_provider import get_model
+    from pytorchcv_amd.models.common.conv import pre_conv3x3_block
+    net = get_model("mobilenetv2_w1").eval()
+    net.load_state_dict(util.model_state("mobilenetv2_w1", net.state_dict()), strict=True)
+    net = net.to(cuda_device)
+    x = util.synth_input(2, seed=5).to(cuda_device)
+    unit = net.features.stage2.unit1
+    with torch.no_grad():
+        a = engine.from_nchw(x, "fp16", stem=True)
+        h = net.features.init_block(a)
+        want = engine.to_nchw(unit(net.features.stage1(h)))
+        xin = engine.to_nchw(net.features.stage1(h))            # fp32 NCHW copy of fp16 values: converts back exactly
+        got = unit(xin)
+    assert engine.compute_dtype_of(unit) == "fp16"
+    assert torch.equal(got, want)
+    blk = pre_conv3x3_block(in_channels=16, out_channels=16, return_preact=True)
+    sd = util.synth_state_dict(blk.state_dict(), seed=9)
+    sd["conv.weight"] = sd["conv.weight"] * BIG
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.eval().to(cuda_device), "fp16")
+    with torch.no_grad():
+        y, pre = blk(util.synth_input(2, 16, 12, 12, seed=3).to(cuda_device))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(y).all()), "an fp16 overflow inside a pre-activation block called with a tensor must poison its result"

@@ -73,6 +73,9 @@ def test_model_fp32_matches_reference_golden(name, cuda_device):
     assert torch.equal(y.argmax(1), logits.argmax(1))
 
 
+_BF16_KNOWN_MISS_BOUND = 3e-2      # bf16 logits of the fp16-default families against the reference's fp32 forward (measured 1.3e-2 .. 2.2e-2)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name", util.MODELS)
 def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_device):
@@ -94,6 +97,13 @@ def test_model_16bit_matches_quantisation_matched_oracle(name, dtype, cuda_devic
     assert torch.equal(y.argmax(1), logits.argmax(1)), "top-1 differs from the reference forward"
     if dtype == "fp16" or dtype == _auto_dtype(name):
         assert raw <= NORTH_STAR_16BIT, "{} {}: max |d| vs the fp32 reference golden {:.3e} > 1e-2".format(name, dtype, raw)
+    else:
+        # bf16 on a family whose default mode is fp16 (MobileNetV2 / V3, EfficientNet): the north star's literal 1e-2 is NOT met in
+        # bf16 there (measured 1.3e-2 .. 2.2e-2: 8-bit-mantissa weights on [0, 6]-bounded activations) - which
+        # is why "auto" is fp16 for them. Asserted as what it is, a known miss with a measured bound: a regression of the bf16 mode
+        # on these families (> 3e-2) fails, and so does a silent improvement below 1e-2 (then bf16 may become their default again).
+        assert NORTH_STAR_16BIT < raw <= _BF16_KNOWN_MISS_BOUND, \
+            "{} bf16 vs the fp32 reference golden: {:.3e}, expected inside (1e-2, {:.0e}]".format(name, raw, _BF16_KNOWN_MISS_BOUND)
 
 
 # BASELINE.json configs 2-4 (+ resnet18 at the same batch): the batches bench.py times. At these sizes every persistent kernel

@@ -145,4 +145,28 @@ def test_bench_two_ranks_share_this_gpu_end_to_end(cuda_device):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and "rehearsal" in out
     assert out["config"]["launch"].startswith("2 hipGraphs in flight")      # the all-gather of every step rides on its slot's stream
     wb = out["weights_broadcast"]
-    assert wb and wb["messages"] >= 1 and wb["bytes"] > 1e6 and wb["replicas_agree"] is True
+    assert wb and wb["messages"] >= 1 and wb["bytes"] > 1e6 and wb["replicas_agree"] is True and wb["seconds"] > 0
+    assert out["config"]["launcher_choice"] == "flags"
+
+
+def test_bench_two_gpus_real_rccl(cuda_device):
+    """`python bench.py --gpus 2` with one GPU per rank and RCCL (backend "nccl") for the weight broadcast, the replica check and the
+    per-step all-gather - the driver's multi-GPU tier at its smallest size. Runs where the box has two GPUs; skipped on the one-GPU
+    test boxes (the same path runs there as a rehearsal, above). Weak and strong (fixed global batch) scaling lines."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one rank per GPU over RCCL / xGMI)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PCV_BENCH_REHEARSE")}
+    env.update(PYTHONPATH=root, PCV_BENCH_TIMEOUT_S="500")
+    for extra, batch in ((["--batch", "32"], 64), (["--scaling", "strong", "--global-batch", "64"], 64)):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "resnet18_bs256", "--steps", "3",
+                            "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["n_gpus"] == 2 and out["config"]["global_batch"] == batch and "rehearsal" not in out
+        assert out["config"]["launcher_choice"].startswith("fixed for multi-rank")
+        assert out["weights_broadcast"]["replicas_agree"] is True and out["weights_broadcast"]["seconds"] > 0

@@ -204,6 +204,22 @@ def test_get_model_contract():
         get_resnet(blocks=19)
 
 
+def test_auto_dtype_is_resolved_once_per_family():
+    """ "auto" resolves to the family's 16-bit mode on EVERY sub-module (`net.features(x)` or a unit called with an NCHW
+    tensor ran an fp16-family backbone in bf16): every module of a net reports the type the net itself reports."""
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.model_provider import get_model
+    for name, want in (("mobilenetv2_w1", "fp16"), ("mobilenetv3_small_w1", "fp16"), ("efficientnet_b0", "fp16"), ("resnet18", "bf16"),
+                       ("preresnet18", "bf16")):
+        net = get_model(name).eval()
+        if os.environ.get("PCV_AMD_DTYPE", "auto") == "auto":
+            assert engine.compute_dtype_of(net) == want
+        kinds = {engine.compute_dtype_of(m) for m in net.modules()}
+        assert kinds == {engine.compute_dtype_of(net)}, (name, kinds)
+        engine.set_compute_dtype(net, "bf16")
+        assert {engine.compute_dtype_of(m) for m in net.modules()} == {"bf16"}
+
+
 @pytest.mark.parametrize("name", util.MODELS)
 def test_param_counts_and_state_dict_manifest(name):
     """Known answers of the reference's own asserts + the key/shape/dtype manifest captured from the reference."""

@@ -1,4 +1,4 @@
-"""Dev tool (diagnostic build: make -C pytorchcv_amd/csrc EXTRA=-DD3W_CYCLES): phase stamps of every block of d3w_kernel -
+"""Dev tool (diagnostic build: make -C pytorchcv_amd/csrc EXTRA="-DD3W_CYCLES -DPCV_DBG_FLAGS"): phase stamps of every block of d3w_kernel -
 entry -> prologue barrier -> start of the last epilogue -> exit (s_memrealtime, 10 ns units, and shader cycles)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
