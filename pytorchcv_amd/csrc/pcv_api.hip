@@ -12,6 +12,7 @@
 #include "igemm_inst.hpp"
 #include "d3q_inst.hpp"
 #include "d3w_inst.hpp"
+#include "d3c_conv.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
@@ -39,6 +40,8 @@ D3Q1_SHAPES(D3Q1_DECLARE, PCV_BF16)
 D3Q1_SHAPES(D3Q1_DECLARE, PCV_F16)
 D3W_SHAPES(D3W_DECLARE, PCV_BF16)
 D3W_SHAPES(D3W_DECLARE, PCV_F16)
+extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
+extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
 
 struct pcv_ctx {
     int device = 0;
@@ -55,6 +58,7 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
+    int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
     int dw_flags = 0;           // tuning: bit 0 = non-temporal stores in the depthwise kernels
@@ -437,7 +441,9 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
       reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW, KS, NSA>)}},
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
+static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
 static int enable_d3x3(pcv_ctx* ctx) {
+    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
@@ -809,6 +815,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "max_blocks") ctx->max_blocks = value;
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "d3w") ctx->use_d3w = value;
+    else if (k == "d3c") ctx->use_d3c = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "stem32") ctx->use_stem32 = value;
     else if (k == "d1x1") ctx->use_d1x1 = value;
@@ -1105,6 +1112,7 @@ enum ConvKernel {
     CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
+    CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
     CK_D3Q,         // d3q_conv.hpp: dense 3x3 / s1 / p1, 16 bit
     CK_D3Q_1X1,     // d3q_conv.hpp in its 1x1 mode: K-heavy pointwise layers
@@ -1182,6 +1190,13 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
     if (P.conv3 && !A.gate && ctx->use_d3x3 != 0 && d->dtype != PCV_F32 && clamp_acts && A.scale && A.shift &&
         G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull &&
         G.xbytes + 2ull * (unsigned long long)d->W * d->Cin * 2ull < 0x80000000ull) {
+        // 64 input channels on a 56-wide map (ResNet stage 1): 4-row tiles of one image per 64-channel tile; automatic choice from
+        // two tiles per CU up (below that the 6-row patch prologue is not amortised)
+        if (ctx->use_d3c != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3c > 0) && (ctx->use_d3w <= 0 || ctx->use_d3c > 0) && d->Cin == D3CCfg::BM &&
+            d->W == D3CCfg::W && G.cpitch == d->Cin && G.wpitch == d->W) {
+            const long long tiles = (long long)((d->Cout + 63) / 64) * d->N * ((d->H + D3CCfg::ROWS - 1) / D3CCfg::ROWS);
+            if (ctx->use_d3c > 0 || tiles >= 2ll * block_slots(ctx, 1)) { R.kernel = CK_D3C; return R; }
+        }
         if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
             R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
                                        : pick_d3w((long long)G.M64, d->Cout, (long long)block_slots(ctx, 1));
@@ -1312,14 +1327,16 @@ static int launch_gconv_flat(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPla
 // d3q_kernel, both modes: `one` = the 1x1 mode (kD1 shapes; H / W / HW describe the OUTPUT map, a strided 1x1 reads every
 // stride-th pixel), else the dense 3x3 mode (kD3 shapes)
 static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, int shape, bool one,
-                      bool wide = false) {
+                      bool wide = false, bool c64 = false) {
     const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
     const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * 2ull;
     if (ypitch < d->Cout || (ypitch * 2) % 16 != 0)
         return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
     if (ybytes >= 0x80000000ull)
         return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
-    const D3Shape& S = wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape]);       // wide: d3w_kernel (512 threads), same parameter block
+    static const D3Shape kC64 = {D3CCfg::BM, D3CCfg::BP, D3CCfg::LDS, {kD3C[0], kD3C[1]}};
+    // wide: d3w_kernel (512 threads); c64: d3c_kernel (256 threads, tiles = 4 output rows of one image); same parameter block
+    const D3Shape& S = c64 ? kC64 : (wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape]));
     D3Params q;
     std::memset(&q, 0, sizeof(q));
     q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
@@ -1338,19 +1355,20 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
         q.div_w = make_fastdiv((uint32_t)d->W);
         q.stride = 1;
         q.nk = P.nk; q.slices = d->Cin / 64;
-        q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
+        q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);       // (diagnostic builds: -DD3X3_STAMPS, -DD3W_CYCLES, -DD3C_CYCLES)
     }
     q.div_hw = make_fastdiv((uint32_t)q.HW);
     q.act = d->act; q.post_act = d->post_act;
     q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
-    const long long nT = ((long long)((G.M64 + S.BP - 1) / S.BP)) * q.nChTiles;
+    const long long nT = c64 ? (long long)d->N * ((d->H + D3CCfg::ROWS - 1) / D3CCfg::ROWS) * q.nChTiles
+                             : ((long long)((G.M64 + S.BP - 1) / S.BP)) * q.nChTiles;
     if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
     q.nTiles = (int)nT;
     const long long slots = block_slots(ctx, 1);
     long long nb = slots < nT ? slots : nT;
     nb = (nb + 7) / 8 * 8;
     void* args[] = {&q};
-    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(wide ? 512 : 768), args, (size_t)S.lds, A.stream));
+    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(c64 ? 256 : (wide ? 512 : 768)), args, (size_t)S.lds, A.stream));
     return PCV_OK;
 }
 
@@ -1488,6 +1506,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         case CK_STEM: return launch_stem(ctx, d, P, G, A);
         case CK_GCONV_ROWS: return launch_gconv_rows(ctx, d, P, G, A, R.rows);
         case CK_GCONV_FLAT: return launch_gconv_flat(ctx, d, P, G, A);
+        case CK_D3C: return launch_d3q(ctx, d, P, G, A, 0, false, false, true);
         case CK_D3W: return launch_d3q(ctx, d, P, G, A, R.shape, false, true);
         case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
         case CK_D3Q_1X1: return launch_d3q(ctx, d, P, G, A, R.shape, true);

@@ -158,7 +158,7 @@ def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device
     with torch.no_grad():
         xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
         rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
-        with util.tuning(max_blocks=grid, d3x3=d3, d3w=dw):
+        with util.tuning(max_blocks=grid, d3x3=d3, d3w=dw, d3c=0):
             yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
         if kernel != "generic":
             # same K order, same MFMA sequence per accumulator, same epilogue arithmetic: bit-identical to the generic kernel
@@ -576,6 +576,46 @@ def test_stem_full_batch_is_repeatable(kind, cuda_device):
         for rep in range(10):
             y = blk(engine.from_nchw(x, "bf16", stem=True)).t
             assert torch.equal(y, want), "pass {}: {} images differ".format(rep, int((y != want).flatten(1).any(1).sum()))
+
+
+_D3C_SHAPES = [  # (N, Cout, H, residual): 64 input channels on 56-wide maps (csrc/d3c_conv.hpp: weights in registers, 4-row tiles)
+    (2, 64, 56, False), (3, 64, 56, True), (2, 128, 30, False), (1, 192, 5, True), (5, 72, 9, True), (1, 64, 1, False), (40, 64, 4, True),
+]
+
+
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _D3C_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D3C_SHAPES])
+def test_conv3x3_c64_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_device):
+    """d3c_kernel (64 input channels, 56-wide maps: ResNet stage 1, reference resnet.py:49,56,120-127): bit-identical to the generic
+    implicit GEMM (same K order, same MFMA chain per accumulator) on whole and partial row tiles (H % 4 != 0), several channel
+    tiles (weights reloaded per run of tiles), ragged channel counts, with and without the residual epilogue; and within the
+    16-bit bound of the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, Cout, H, use_res = shape
+    C, W = 64, 56
+    blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=78)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=23)
+    res = util.synth_input(N, Cout, H, W, seed=24) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        with util.tuning(max_blocks=grid, d3c=1):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        with util.tuning(d3x3=0):
+            yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        assert torch.equal(yh.t, yg.t), "d3c differs from the generic implicit GEMM in {} elements".format(int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
 _D1_SHAPES = [  # (N, Cin, Cout, H, W, residual[, stride]): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
