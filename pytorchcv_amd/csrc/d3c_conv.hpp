@@ -133,88 +133,146 @@ __device__ __forceinline__ void d3c_body(const D3Params& p, char* smem) {
         y0 = (pt - n * tilesPerImage) * G::ROWS;
     };
 
-    f32x4 acc[2][7];
-    frag b[2][7];
-    uint32_t bs[7][3];                                            // ba + this tile's slot (set per tile: 21 adds instead of 7 per K-half)
-    // fragments of K-half kh (K-step kh >> 1 = filter row r, column q; half h)
-    auto reads = [&](auto SETc, int kh) __attribute__((always_inline)) {
-        constexpr int SET = decltype(SETc)::value;
-        const int ks = kh >> 1, r = ks / 3, q = ks - 3 * r, h = kh & 1;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const uint32_t a = bs[j][q] ^ (uint32_t)(h << 6);                       // (kc + 4) ^ key = (kc ^ key) ^ 4: bit 6 of the address
-#if defined(D3C_EXP) && D3C_EXP >= 3
-            if (kh < 2)
-#endif
-            b[SET][j] = *reinterpret_cast<lds_fptr>((size_t)a + (size_t)(r * G::PITCH * 128));
-        }
-    };
-    auto mfmas = [&](auto SETc, int kh) __attribute__((always_inline)) {
-        constexpr int SET = decltype(SETc)::value;
-#pragma unroll
-        for (int j = 0; j < 7; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][j] = Mma<DT>::run(A[kh][i], b[SET][j], acc[i][j]);
+    // K loop order: PIXEL BLOCK outer, K-half inner. A block's two accumulators (its 16 pixels x this wave's 32 channels) run
+    // through all 18 K-halves (36 MFMAs; a 16x16x32 chain on one accumulator issues at the full rate), then the block is
+    // finished and stored WHILE the next block's MFMAs run - the vector ALU work of the epilogue (1 960 of a tile's 7 580 cycles
+    // when it ran behind the K loop of all seven blocks) goes under the matrix pipe, with two accumulator pairs instead of seven.
+    // One fragment read per step (block j, K-half kh), requested RD steps ahead into a ring of fragment values.
+    constexpr int RD = 5, RING = 8, NSTEP = 7 * 18;
+    f32x4 cacc[2][2];                                             // [block parity][channel half]
+    frag bq[RING];
+    uint32_t bs[7][3];                                            // ba + this tile's slot (set per tile)
+    auto rd = [&](auto STc) __attribute__((always_inline)) {
+        constexpr int st = decltype(STc)::value;
+        constexpr int j = st / 18, kh = st - 18 * j, ks = kh >> 1, r = ks / 3, q = ks - 3 * r, h = kh & 1;
+        const uint32_t a = bs[j][q] ^ (uint32_t)(h << 6);                           // (kc + 4) ^ key = (kc ^ key) ^ 4: bit 6 of the address
+        bq[st % RING] = *reinterpret_cast<lds_fptr>((size_t)a + (size_t)(r * G::PITCH * 128));
     };
     // Activations none / ReLU / ReLU6 as BRANCH-FREE clamps to launch-uniform bounds (-inf / 0, +inf / 6; IEEE-754-2019 maximum /
     // minimum: a NaN stays a NaN, max(v, -inf) = v and min(v, +inf) = v bit for bit): the uniform switch of `clampn` is a dozen scalar
     // branches per pixel block, and a wave that is alone on its SIMD pays every one of them (3 100 cycles per tile's epilogue).
     const float alo = (p.act == PCV_ACT_RELU || p.act == PCV_ACT_RELU6) ? 0.f : -INFINITY, ahi = p.act == PCV_ACT_RELU6 ? 6.f : INFINITY;
     const float plo = (p.post_act == PCV_ACT_RELU || p.post_act == PCV_ACT_RELU6) ? 0.f : -INFINITY, phi = p.post_act == PCV_ACT_RELU6 ? 6.f : INFINITY;
-    // Epilogue: v = acc * scale + shift -> act -> (+ residual) -> post_act -> one 16-byte NHWC store per pixel block (d3q_conv.hpp).
-    // The residual tile is requested in front of the tile's last K-step pair (`res_request`), not inside the epilogue.
-    u32x4 rr[7];
-    auto res_request = [&](int chT, int nn, int yy0) __attribute__((always_inline)) {
-        const int ch0 = chT * G::BM + wc * 32 + 8 * fq;
-        const int mTile = (nn * p.H + yy0) * G::W;
-        const int mEnd = (nn * p.H + (yy0 + G::ROWS < p.H ? yy0 + G::ROWS : p.H)) * G::W;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int m = mTile + wp * 112 + 16 * j + fr;
-            const uint32_t roff = (ch0 < p.Cout && m < mEnd) ? (uint32_t)((m * p.Cout + ch0) * 2) : 0x80000000u;
-            rr[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
-        }
-    };
-    auto epilogue = [&](auto HRc, int chT, int nn, int yy0) __attribute__((always_inline)) {
+    const float clo = alo > plo ? alo : plo, chi = ahi < phi ? ahi : phi;
+    // One pixel block's epilogue, in FOUR parts of two values each (v = acc * scale + shift -> act -> (+ residual) -> post_act ->
+    // packed pair; d3q_conv.hpp) + the 16-byte NHWC store. The parts of block j - 1 are written BETWEEN the steps of block j (its
+    // accumulator pair is the other one), so that the vector ALU work sits under the next block's MFMAs in program order too - left
+    // to the scheduler, a block's epilogue ran as one run of ~45 VALU instructions behind its last MFMA, the matrix pipe idle.
+    u32x4 rrq[7];                                                 // the tile's residual pieces (requested at the tile's start)
+    u32x4 opend;                                                  // the packed outputs of the block being finished
+    auto epi_part = [&](auto HRc, auto Jc, auto Ec, F16Guard<DT>& guard) __attribute__((always_inline)) {
         constexpr bool HR = decltype(HRc)::value;
-        const int ch0 = chT * G::BM + wc * 32 + 8 * fq;
-        const bool chok = ch0 < p.Cout;
-        const int mTile = (nn * p.H + yy0) * G::W;                 // first pixel of the tile (whole image rows: flat NHWC index)
-        const int mEnd = (nn * p.H + (yy0 + G::ROWS < p.H ? yy0 + G::ROWS : p.H)) * G::W;
-        F16Guard<DT> guard;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int m = mTile + wp * 112 + 16 * j + fr;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = acc[0][j][e] * es0[e] + eh0[e];
-                v[4 + e] = acc[1][j][e] * es1[e] + eh1[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], alo), ahi);
-            if constexpr (HR) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float lo, hi;
-                    unpack2<DT>(rr[j][e], lo, hi);
-                    v[2 * e] += lo;
-                    v[2 * e + 1] += hi;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], plo), phi);
-            guard.see(v);
-            u32x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-            const uint32_t boff = (chok && m < mEnd) ? (uint32_t)((m * p.Ypitch + ch0) * 2) : 0x80000000u;     // (the host keeps y below 2 GiB)
-            __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
+        constexpr int j = decltype(Jc)::value, e = decltype(Ec)::value;          // output dword e: values 2 e, 2 e + 1 of the lane's 8 channels
+        constexpr int half = e >> 1, k0 = 2 * (e & 1);                                // accumulator (channel half), element pair
+        const f32x4& sc = half == 0 ? es0 : es1;
+        const f32x4& sh = half == 0 ? eh0 : eh1;
+        float v0 = cacc[j & 1][half][k0] * sc[k0] + sh[k0], v1 = cacc[j & 1][half][k0 + 1] * sc[k0 + 1] + sh[k0 + 1];
+        if constexpr (HR) {
+            v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, alo), ahi);
+            v1 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v1, alo), ahi);
+            float lo, hi;
+            unpack2<DT>(rrq[j][e], lo, hi);
+            v0 += lo;
+            v1 += hi;
+            v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, plo), phi);
+            v1 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v1, plo), phi);
+        } else {
+            // nothing between the two activations: clamp(clamp(v, alo, ahi), plo, phi) = clamp(v, max(alo, plo), min(ahi, phi)) for
+            // these bounds (0 / -inf below, 6 / +inf above), NaN and signed zero included
+            v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, clo), chi);
+            v1 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v1, clo), chi);
         }
+        guard.see2(v0, v1);
+        opend[e] = pack2<DT>(v0, v1);
+    };
+    auto epi_store = [&](int j, int ch0, int mTile, int mEnd) __attribute__((always_inline)) {
+        const int m = mTile + wp * 112 + 16 * j + fr;
+        const uint32_t boff = (ch0 < p.Cout && m < mEnd) ? (uint32_t)((m * p.Ypitch + ch0) * 2) : 0x80000000u;     // (the host keeps y below 2 GiB)
+        __builtin_amdgcn_raw_buffer_store_b128(opend, yrsrc, boff, 0, 0);
+    };
+    // one tile: 126 steps; the 11 pieces of the NEXT tile's patch go out at steps 4, 15, 26, ... (into the other slot: every wave left
+    // it before the barrier that ended the last tile)
+    auto tile_steps = [&](auto HRc, int slot, int ch0, int mTile, int mEnd) __attribute__((always_inline)) {
+        constexpr bool HR = decltype(HRc)::value;
+        F16Guard<DT> guard;
+        if constexpr (HR) {
+            // the skip tensor's pieces of the whole tile, in FRONT of this tile's LDS-DMA pieces: vmcnt retires in order, and a residual
+            // load issued behind a piece would make its consumer wait for that piece's trip to HBM
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int m = mTile + wp * 112 + 16 * j + fr;
+                const uint32_t roff = (ch0 < p.Cout && m < mEnd) ? (uint32_t)((m * p.Cout + ch0) * 2) : 0x80000000u;
+                rrq[j] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
+            }
+        }
+        rd(std::integral_constant<int, 0>{}); rd(std::integral_constant<int, 1>{}); rd(std::integral_constant<int, 2>{});
+        rd(std::integral_constant<int, 3>{}); rd(std::integral_constant<int, 4>{});
+        static_assert(RD == 5, "the five reads above");
+        // (every index below is a template constant: a `#pragma unroll` loop of 126 large steps was only partly unrolled and its
+        // run-time indices sent the weight fragments to scratch)
+        auto step = [&](auto STc) __attribute__((always_inline)) {
+            constexpr int st = decltype(STc)::value;
+            constexpr int j = st / 18, kh = st - 18 * j;
+            if constexpr (st + RD < NSTEP) rd(std::integral_constant<int, st + RD>{});
+#if !defined(D3C_EXP) || D3C_EXP < 2
+            if constexpr (st == 4) dma_piece(std::integral_constant<int, 0>{}, slot ^ 1);
+            if constexpr (st == 15) dma_piece(std::integral_constant<int, 1>{}, slot ^ 1);
+            if constexpr (st == 26) dma_piece(std::integral_constant<int, 2>{}, slot ^ 1);
+            if constexpr (st == 37) dma_piece(std::integral_constant<int, 3>{}, slot ^ 1);
+            if constexpr (st == 48) dma_piece(std::integral_constant<int, 4>{}, slot ^ 1);
+            if constexpr (st == 59) dma_piece(std::integral_constant<int, 5>{}, slot ^ 1);
+            if constexpr (st == 70) dma_piece(std::integral_constant<int, 6>{}, slot ^ 1);
+            if constexpr (st == 81) dma_piece(std::integral_constant<int, 7>{}, slot ^ 1);
+            if constexpr (st == 92) dma_piece(std::integral_constant<int, 8>{}, slot ^ 1);
+            if constexpr (st == 103) dma_piece(std::integral_constant<int, 9>{}, slot ^ 1);
+            if constexpr (st == 114) dma_piece(std::integral_constant<int, 10>{}, slot ^ 1);
+#endif
+            if constexpr (kh == 0) {
+                cacc[j & 1][0] = Mma<DT>::run(A[0][0], bq[st % RING], (f32x4){0.f, 0.f, 0.f, 0.f});
+                cacc[j & 1][1] = Mma<DT>::run(A[0][1], bq[st % RING], (f32x4){0.f, 0.f, 0.f, 0.f});
+            } else {
+                cacc[j & 1][0] = Mma<DT>::run(A[kh][0], bq[st % RING], cacc[j & 1][0]);
+                cacc[j & 1][1] = Mma<DT>::run(A[kh][1], bq[st % RING], cacc[j & 1][1]);
+            }
+            // keep the fragment of two steps ago alive up to here: its register is not handed to a new read directly behind the MFMAs
+            // that read it (write-after-read on an MFMA source operand stalls the LDS instruction until the matrix pipe has taken it)
+            // (anchored behind this step's MFMAs through their accumulator: an asm with only the fragment as operand floats up to the
+            // fragment's definition and keeps nothing alive)
+            if constexpr (st >= 2) asm volatile("" ::"v"(bq[(st - 2) % RING]), "a"(cacc[j & 1][1]));
+#if !defined(D3C_EXP) || D3C_EXP < 1
+            if constexpr (j >= 1) {                                 // block j - 1 is finished under this block's MFMAs
+                typedef std::integral_constant<int, j - 1> JP;
+                if constexpr (kh == 1) epi_part(HRc, JP{}, std::integral_constant<int, 0>{}, guard);
+                if constexpr (kh == 5) epi_part(HRc, JP{}, std::integral_constant<int, 1>{}, guard);
+                if constexpr (kh == 9) epi_part(HRc, JP{}, std::integral_constant<int, 2>{}, guard);
+                if constexpr (kh == 13) epi_part(HRc, JP{}, std::integral_constant<int, 3>{}, guard);
+                if constexpr (kh == 15) epi_store(j - 1, ch0, mTile, mEnd);
+            }
+#endif
+        };
+        auto run = [&](auto... Sc) __attribute__((always_inline)) { (step(Sc), ...); };
+        auto block = [&](auto Jc) __attribute__((always_inline)) {      // the 18 steps of pixel block J
+            constexpr int B0 = decltype(Jc)::value * 18;
+            run(std::integral_constant<int, B0>{}, std::integral_constant<int, B0 + 1>{}, std::integral_constant<int, B0 + 2>{},
+                std::integral_constant<int, B0 + 3>{}, std::integral_constant<int, B0 + 4>{}, std::integral_constant<int, B0 + 5>{},
+                std::integral_constant<int, B0 + 6>{}, std::integral_constant<int, B0 + 7>{}, std::integral_constant<int, B0 + 8>{},
+                std::integral_constant<int, B0 + 9>{}, std::integral_constant<int, B0 + 10>{}, std::integral_constant<int, B0 + 11>{},
+                std::integral_constant<int, B0 + 12>{}, std::integral_constant<int, B0 + 13>{}, std::integral_constant<int, B0 + 14>{},
+                std::integral_constant<int, B0 + 15>{}, std::integral_constant<int, B0 + 16>{}, std::integral_constant<int, B0 + 17>{});
+        };
+        block(std::integral_constant<int, 0>{}); block(std::integral_constant<int, 1>{}); block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{}); block(std::integral_constant<int, 4>{}); block(std::integral_constant<int, 5>{});
+        block(std::integral_constant<int, 6>{});
+#if !defined(D3C_EXP) || D3C_EXP < 1
+        {                                                           // the last block's epilogue: on its own
+            typedef std::integral_constant<int, 6> JL;
+            epi_part(HRc, JL{}, std::integral_constant<int, 0>{}, guard); epi_part(HRc, JL{}, std::integral_constant<int, 1>{}, guard);
+            epi_part(HRc, JL{}, std::integral_constant<int, 2>{}, guard); epi_part(HRc, JL{}, std::integral_constant<int, 3>{}, guard);
+            epi_store(6, ch0, mTile, mEnd);
+        }
+#endif
         guard.commit(p.ovf);
     };
-    typedef std::integral_constant<int, 0> S0;
-    typedef std::integral_constant<int, 1> S1;
 
     // ---- prologue: the first tile's patch ----
     int chTile, n, y0;
@@ -251,51 +309,19 @@ __device__ __forceinline__ void d3c_body(const D3Params& p, char* smem) {
             uint64_t c0__ = 0, c1__ = 0, c2__ = 0;
             if (stamp__) c0__ = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // 18 K-halves from this tile's patch; the fragments of K-half kh + 1 are requested before the MFMAs of kh; the 11 pieces of the
-            // NEXT tile's patch go out in the first six K-step pairs (into the other slot: every wave left it before the barrier that ended
-            // the last tile).
-            // Fragment reads and MFMAs are kept in SEPARATE scheduling regions: left alone, the compiler put the read that refills a
-            // fragment register directly behind the MFMA pair that reads it (write-after-read on the MFMA's source operand: the LDS
-            // instruction waits for the matrix pipe), and a tile's K loop took 10 100 cycles instead of 5 060.
-            reads(S0{}, 0);
-#pragma unroll
-            for (int pi = 0; pi < 9; ++pi) {
-                const int kh = 2 * pi;
-                reads(S1{}, kh + 1);
-#if !defined(D3C_EXP) || D3C_EXP < 2
-                if (pi == 0) { dma_piece(std::integral_constant<int, 0>{}, slot ^ 1); dma_piece(std::integral_constant<int, 1>{}, slot ^ 1); }
-                if (pi == 1) { dma_piece(std::integral_constant<int, 2>{}, slot ^ 1); dma_piece(std::integral_constant<int, 3>{}, slot ^ 1); }
-                if (pi == 2) { dma_piece(std::integral_constant<int, 4>{}, slot ^ 1); dma_piece(std::integral_constant<int, 5>{}, slot ^ 1); }
-                if (pi == 3) { dma_piece(std::integral_constant<int, 6>{}, slot ^ 1); dma_piece(std::integral_constant<int, 7>{}, slot ^ 1); }
-                if (pi == 4) { dma_piece(std::integral_constant<int, 8>{}, slot ^ 1); dma_piece(std::integral_constant<int, 9>{}, slot ^ 1); }
-                if (pi == 5) { dma_piece(std::integral_constant<int, 10>{}, slot ^ 1); }
-#endif
-                if (pi == 8 && has_res) res_request(chTile, n, y0);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(S0{}, kh);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kh + 2 < 18) reads(S0{}, kh + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(S1{}, kh + 1);
-                __builtin_amdgcn_sched_barrier(0);
+            {
+                const int ch0 = chTile * G::BM + wc * 32 + 8 * fq;
+                const int mTile = (n * p.H + y0) * G::W;             // first pixel of the tile (whole image rows: flat NHWC index)
+                const int mEnd = (n * p.H + (y0 + G::ROWS < p.H ? y0 + G::ROWS : p.H)) * G::W;
+                if (has_res) tile_steps(std::true_type{}, slot, ch0, mTile, mEnd);
+                else tile_steps(std::false_type{}, slot, ch0, mTile, mEnd);
             }
 #ifdef D3C_CYCLES
-            if (stamp__) c1__ = __builtin_amdgcn_s_memtime();
+            if (stamp__) c2__ = c1__ = __builtin_amdgcn_s_memtime();
 #endif
-#if !defined(D3C_EXP) || D3C_EXP < 1
-            if (has_res) epilogue(std::true_type{}, chTile, n, y0);
-            else epilogue(std::false_type{}, chTile, n, y0);
-#endif
-#ifdef D3C_CYCLES
-            if (stamp__) c2__ = __builtin_amdgcn_s_memtime();
-#endif
-            // the next patch has landed (the epilogue's 7 stores, issued behind the pieces and the residual loads, may stay in flight);
-            // every wave is done with this one
-            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            // the next patch has landed (behind its last piece, step 114, only the last block's store - and, with a skip tensor, its long
+            // consumed residual load - were issued); every wave is done with this patch
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             d3q_sync();
 #ifdef D3C_CYCLES
             if (stamp__ && lane == 0) {
