@@ -38,12 +38,15 @@
 // WC x WP: wave grid (channels x pixels), 8 waves. CBW / PBW: 16-row blocks per wave (channels / pixels).
 // NSA_: slots of the weight ring (3: the tile of K-step s + 2 is issued during K-step s; 2: the tile of s + 1, due at the end of s - for
 //     block tiles whose activation slots leave no room for a third weight tile).
+// TRIM: pixel blocks cut from the END of the tile: the waves still run PBW blocks each (the barrier interval is set by the longest
+//     wave), but the tile covers - stages, stores - 16 TRIM pixels less. 128 x 416 (TRIM 2 of 4 x 7 blocks): two activation slots of
+//     418 rows leave room for the three-slot weight ring that 128 x 448 has no LDS for.
 // KS: K-halves (32 elements each) per barrier interval - 1: four intervals per K-step (wave tiles of 24-28 accumulators),
 //     2: two intervals per K-step, both halves' fragments read at once (wave tiles of 14 accumulators: 14 MFMAs are too short an interval).
-template <int WC, int WP, int CBW, int PBW, int KS, int NSA_ = 3> struct D3WCfg {
+template <int WC, int WP, int CBW, int PBW, int KS, int NSA_ = 3, int TRIM = 0> struct D3WCfg {
     static constexpr int THREADS = 512;
     static constexpr int BM = 16 * CBW * WC;                 // channel rows per block tile
-    static constexpr int BP = 16 * PBW * WP;                 // pixel rows per block tile
+    static constexpr int BP = 16 * (PBW * WP - TRIM);        // pixel rows per block tile (the last wave's last TRIM blocks lie outside it)
     static constexpr int NPA = BM / 8;                       // 1 KB DMA pieces (8 rows x 128 B) of one weight tile
     static constexpr int WLW = NPA / 8;                      // ... per wave
     static constexpr int BROWS = (BP + 2 + 7) / 8 * 8;       // rows of one activation tile: flat pixels P0 - 1 .. P0 + BP, padded
@@ -75,9 +78,9 @@ template <int WC, int WP, int CBW, int PBW, int KS, int NSA_ = 3> struct D3WCfg 
 #if defined(__HIP_DEVICE_COMPILE__)
 // One wave's whole persistent loop. GRP 0: waves 0-3; GRP 1: waves 4-7, one barrier interval behind (separate straight-line
 // instantiations: a per-interval `if (group)` makes the register allocator join both groups' states).
-template <int DT, int WC, int WP, int CBW, int PBW, int KS, int NSA_, int GRP>
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, int NSA_, int TRIM, int GRP>
 __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const int wave) {
-    typedef D3WCfg<WC, WP, CBW, PBW, KS, NSA_> G;
+    typedef D3WCfg<WC, WP, CBW, PBW, KS, NSA_, TRIM> G;
     constexpr int BM = G::BM, BP = G::BP, WLW = G::WLW, XLW = G::XLW, NSA = G::NSA, AHEAD = NSA - 1;
     typedef typename Mma<DT>::frag frag;
     typedef __attribute__((address_space(3))) char lds_char;
@@ -298,7 +301,7 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
                         const int j = j0 + jj;
                         if (j < PBW) {
                             const int m = mBase + 16 * j;
-                            const uint32_t roff = (chok && m < p.M) ? (uint32_t)(((size_t)m * p.Cout + ch0) * 2) : 0x80000000u;
+                            const uint32_t roff = (chok && m < p.M && (TRIM == 0 || m - tileP0 < BP)) ? (uint32_t)(((size_t)m * p.Cout + ch0) * 2) : 0x80000000u;
                             rr[jj] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
                         }
                     }
@@ -325,11 +328,11 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
                             }
                         }
                         clampn<8>(v, pact);
-                        guard.see(v);
+                        if (TRIM == 0 || wp * PBW + j < PBW * WP - TRIM) guard.see(v);      // (a block past a trimmed tile's end holds garbage)
                         u32x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
-                        const bool ok = chok && m < p.M;
+                        const bool ok = chok && m < p.M && (TRIM == 0 || m - tileP0 < BP);      // (trimmed tiles: the blocks past the tile's end)
                         const uint32_t boff = ok ? (uint32_t)(((size_t)m * p.Ypitch + ch0) * 2) : 0x80000000u;
                         __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
                     }
@@ -507,13 +510,13 @@ __device__ __forceinline__ void d3w_body(const D3Params& p, char* smem, const in
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int DT, int WC, int WP, int CBW, int PBW, int KS, int NSA_>
+template <int DT, int WC, int WP, int CBW, int PBW, int KS, int NSA_, int TRIM = 0>
 __global__ __launch_bounds__(512, 2) void d3w_kernel(const D3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically)
-    if (wave < 4) d3w_body<DT, WC, WP, CBW, PBW, KS, NSA_, 0>(p, smem, wave);
-    else d3w_body<DT, WC, WP, CBW, PBW, KS, NSA_, 1>(p, smem, wave);
+    if (wave < 4) d3w_body<DT, WC, WP, CBW, PBW, KS, NSA_, TRIM, 0>(p, smem, wave);
+    else d3w_body<DT, WC, WP, CBW, PBW, KS, NSA_, TRIM, 1>(p, smem, wave);
 #endif  // __HIP_DEVICE_COMPILE__
 }

@@ -40,6 +40,8 @@ D3Q1_SHAPES(D3Q1_DECLARE, PCV_BF16)
 D3Q1_SHAPES(D3Q1_DECLARE, PCV_F16)
 D3W_SHAPES(D3W_DECLARE, PCV_BF16)
 D3W_SHAPES(D3W_DECLARE, PCV_F16)
+D3WT_SHAPES(D3WT_DECLARE, PCV_BF16)
+D3WT_SHAPES(D3WT_DECLARE, PCV_F16)
 extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
 
@@ -439,7 +441,11 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
     {D3WCfg<WC, WP, CBW, PBW, KS, NSA>::BM, D3WCfg<WC, WP, CBW, PBW, KS, NSA>::BP, D3WCfg<WC, WP, CBW, PBW, KS, NSA>::LDS,       \
      {reinterpret_cast<const void*>(d3w_kernel<PCV_BF16, WC, WP, CBW, PBW, KS, NSA>),                                           \
       reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW, KS, NSA>)}},
-static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0)};
+#define D3WT_ROW(DT, WC, WP, CBW, PBW, KS, NSA, TRIM)                                                                                               \
+    {D3WCfg<WC, WP, CBW, PBW, KS, NSA, TRIM>::BM, D3WCfg<WC, WP, CBW, PBW, KS, NSA, TRIM>::BP, D3WCfg<WC, WP, CBW, PBW, KS, NSA, TRIM>::LDS,       \
+     {reinterpret_cast<const void*>(d3w_kernel<PCV_BF16, WC, WP, CBW, PBW, KS, NSA, TRIM>),                                                       \
+      reinterpret_cast<const void*>(d3w_kernel<PCV_F16, WC, WP, CBW, PBW, KS, NSA, TRIM>)}},
+static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
 static int enable_d3x3(pcv_ctx* ctx) {

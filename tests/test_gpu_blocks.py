@@ -134,7 +134,7 @@ _CONV3_SHAPES = [
 
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("kernel", ["generic", "d3x3:auto"] + ["d3x3:{}".format(i) for i in range(8)] +
-                         ["d3w:auto"] + ["d3w:{}".format(i) for i in range(4)])
+                         ["d3w:auto"] + ["d3w:{}".format(i) for i in range(5)])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", _CONV3_SHAPES, ids=["x".join(str(v) for v in s[:5]) + ("_res" if s[5] else "") for s in _CONV3_SHAPES])
 def test_conv3x3_kernel_shapes_vs_oracle(shape, dtype, kernel, grid, cuda_device):
