@@ -62,6 +62,8 @@ def kernel_class_of(name: str):
     head = name.split("(")[0].rstrip()
     if "d3w_kernel" in name or "d3c_kernel" in name:
         return "dense3x3"
+    if "p1r_kernel" in name:
+        return "dense1x1_kheavy"
     if "d3q_kernel" in name:
         return "dense1x1_kheavy" if head.endswith("true>") else "dense3x3"
     if "igemm_conv_kernel" in name:

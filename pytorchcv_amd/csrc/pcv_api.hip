@@ -13,6 +13,7 @@
 #include "d3q_inst.hpp"
 #include "d3w_inst.hpp"
 #include "d3c_conv.hpp"
+#include "p1r_conv.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
 #include "wpair1x1.hpp"
@@ -44,6 +45,11 @@ D3WT_SHAPES(D3WT_DECLARE, PCV_BF16)
 D3WT_SHAPES(D3WT_DECLARE, PCV_F16)
 extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
+#define P1R_DECLARE(CW, CIN)                                                       \
+    extern template __global__ void p1r_kernel<PCV_BF16, CW, CIN>(const D3Params); \
+    extern template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
+P1R_DECLARE(64, 256)
+P1R_DECLARE(32, 512)
 
 struct pcv_ctx {
     int device = 0;
@@ -60,6 +66,7 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
+    int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
     int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
@@ -448,7 +455,14 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
+// p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels)
+#define P1R_ROW(CW, CIN)                                                                   \
+    {P1RCfg<CW, CIN>::BM, P1RCfg<CW, CIN>::BP, P1RCfg<CW, CIN>::LDS,                       \
+     {reinterpret_cast<const void*>(p1r_kernel<PCV_BF16, CW, CIN>), reinterpret_cast<const void*>(p1r_kernel<PCV_F16, CW, CIN>)}}
+static const D3Shape kP1R[2] = {P1R_ROW(64, 256), P1R_ROW(32, 512)};
 static int enable_d3x3(pcv_ctx* ctx) {
+    for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
@@ -822,6 +836,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "d3w") ctx->use_d3w = value;
     else if (k == "d3c") ctx->use_d3c = value;
+    else if (k == "p1r") ctx->use_p1r = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "stem32") ctx->use_stem32 = value;
     else if (k == "d1x1") ctx->use_d1x1 = value;
@@ -1121,6 +1136,7 @@ enum ConvKernel {
     CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
     CK_D3Q,         // d3q_conv.hpp: dense 3x3 / s1 / p1, 16 bit
+    CK_P1R,         // p1r_conv.hpp: 1x1 with 256 / 512 input channels, weights in registers, epilogue under the next pixel block's MFMAs
     CK_D3Q_1X1,     // d3q_conv.hpp in its 1x1 mode: K-heavy pointwise layers
     CK_HEAD,        // head_gemm.hpp: fp32 dense layer on a 1x1 map (classifier)
     CK_IGEMM        // igemm_conv.hpp: everything else
@@ -1216,6 +1232,19 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
         d->stride_h == d->stride_w && d->stride_h <= 2 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
         G.cpitch == d->Cin && G.wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && clamp_acts && A.scale && A.shift &&
         G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
+        // 256 / 512 input channels: the kernel that keeps the weights in registers, where its tiles fill the chip and (almost) every
+        // wave of a channel group has channels to compute; a skip tensor only in the 512-channel form (register budget)
+        if (ctx->use_p1r != 0 && (ctx->use_d1x1 < 0 || ctx->use_p1r > 0) && (d->Cin == 256 || d->Cin == 512) && G.xbytes < 0x80000000ull &&
+            !(d->Cin == 256 && d->has_residual)) {
+            const int shape = d->Cin == 256 ? 0 : 1;
+            const D3Shape& S = kP1R[shape];
+            const long long groups = (d->Cout + S.BM - 1) / S.BM, tiles = ((long long)G.M64 + S.BP - 1) / S.BP * groups;
+            if (ctx->use_p1r > 0 || (d->Cout * 4 >= groups * S.BM * 3 && tiles >= 2ll * block_slots(ctx, 1))) {
+                R.kernel = CK_P1R;
+                R.shape = shape;
+                return R;
+            }
+        }
         R.shape = ctx->use_d1x1 > 0 ? std::min(ctx->use_d1x1 - 1, kD1Count - 1)
                                     : pick_d1x1((long long)G.M64, d->Cout, d->Cin, (long long)block_slots(ctx, 1));
         if (R.shape >= 0) { R.kernel = CK_D3Q_1X1; return R; }
@@ -1333,7 +1362,7 @@ static int launch_gconv_flat(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPla
 // d3q_kernel, both modes: `one` = the 1x1 mode (kD1 shapes; H / W / HW describe the OUTPUT map, a strided 1x1 reads every
 // stride-th pixel), else the dense 3x3 mode (kD3 shapes)
 static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A, int shape, bool one,
-                      bool wide = false, bool c64 = false) {
+                      bool wide = false, bool c64 = false, bool p1r = false) {
     const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
     const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * 2ull;
     if (ypitch < d->Cout || (ypitch * 2) % 16 != 0)
@@ -1342,7 +1371,8 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
         return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
     static const D3Shape kC64 = {D3CCfg::BM, D3CCfg::BP, D3CCfg::LDS, {kD3C[0], kD3C[1]}};
     // wide: d3w_kernel (512 threads); c64: d3c_kernel (256 threads, tiles = 4 output rows of one image); same parameter block
-    const D3Shape& S = c64 ? kC64 : (wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape]));
+    // p1r: p1r_kernel (512 threads; 1x1 mode of the parameter block, channel "tiles" = groups of 512 / 256 channels)
+    const D3Shape& S = p1r ? kP1R[shape] : (c64 ? kC64 : (wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape])));
     D3Params q;
     std::memset(&q, 0, sizeof(q));
     q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
@@ -1356,6 +1386,7 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
         q.div_w = make_fastdiv((uint32_t)P.Wo);
         q.stride = d->stride_h;
         q.nk = d->Cin / 64; q.slices = q.nk;
+        if (p1r) q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);       // (diagnostic builds: -DP1R_CYCLES)
     } else {
         q.H = d->H; q.W = d->W; q.HW = d->H * d->W;
         q.div_w = make_fastdiv((uint32_t)d->W);
@@ -1374,7 +1405,7 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     long long nb = slots < nT ? slots : nT;
     nb = (nb + 7) / 8 * 8;
     void* args[] = {&q};
-    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(c64 ? 256 : (wide ? 512 : 768)), args, (size_t)S.lds, A.stream));
+    HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(c64 ? 256 : ((wide || p1r) ? 512 : 768)), args, (size_t)S.lds, A.stream));
     return PCV_OK;
 }
 
@@ -1515,6 +1546,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         case CK_D3C: return launch_d3q(ctx, d, P, G, A, 0, false, false, true);
         case CK_D3W: return launch_d3q(ctx, d, P, G, A, R.shape, false, true);
         case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
+        case CK_P1R: return launch_d3q(ctx, d, P, G, A, R.shape, true, false, false, true);
         case CK_D3Q_1X1: return launch_d3q(ctx, d, P, G, A, R.shape, true);
         case CK_HEAD: return launch_head(ctx, d, P, G, A);
         default: return launch_igemm(ctx, d, P, G, A, R);

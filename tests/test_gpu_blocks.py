@@ -656,6 +656,48 @@ def test_conv1x1_eight_wave_mode_equals_generic(shape, dtype, grid, cuda_device)
         assert torch.equal(outs[name], outs["generic"]), "{}: {} elements differ".format(name, int((outs[name] != outs["generic"]).sum()))
 
 
+_P1R_SHAPES = [  # (N, Cin, Cout, H, W, residual, stride): 256 / 512 input channels (csrc/p1r_conv.hpp: weights in registers)
+    (4, 512, 1024, 14, 14, True, 1), (3, 512, 2048, 7, 7, True, 1), (2, 512, 256, 28, 28, False, 2), (2, 512, 1024, 28, 28, False, 2),
+    (2, 256, 512, 56, 56, False, 2), (3, 256, 512, 13, 11, False, 1), (2, 256, 600, 9, 7, False, 2), (1, 512, 136, 5, 9, True, 1),
+    (1, 512, 520, 1, 1, False, 1), (5, 256, 1024, 14, 14, True, 1), (2, 512, 512, 17, 5, False, 2),
+]
+
+
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _P1R_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _P1R_SHAPES])
+def test_conv1x1_register_weights_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_device):
+    """p1r_kernel (1x1 with 256 / 512 input channels: ResBottleneck.conv3 / ResNeXtBottleneck.conv3 and the strided identity
+    convolutions, reference resnet.py:128-131,200-206, resnext.py:63-66,107-113): bit-identical to the generic implicit GEMM (same K
+    order, same MFMA chain per accumulator) on whole and partial pixel tiles, several channel groups (weights reloaded per run of
+    tiles), ragged channel counts, stride 1 and 2, with and without the residual epilogue (256 channels + residual: another kernel
+    takes the layer - still equal); and within the 16-bit bound of the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block
+    from oracle import refnet
+    N, C, Cout, H, W, use_res, stride = shape
+    blk = conv1x1_block(in_channels=C, out_channels=Cout, stride=stride).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=85)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=31)
+    res = util.synth_input(N, Cout, (H - 1) // stride + 1, (W - 1) // stride + 1, seed=32) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        with util.tuning(max_blocks=grid, p1r=1):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        with util.tuning(d1x1=0):
+            yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        assert torch.equal(yh.t, yg.t), "p1r differs from the generic implicit GEMM in {} elements".format(int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), stride=stride, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
 @pytest.mark.parametrize("kind", ["mobilenet3x3", "resnet7x7pool", "resnet7x7"])
