@@ -24,6 +24,7 @@
 // (same rounding as the layout kernel: results are bit-identical), one more barrier per tile; the staging DMA of the next tile
 // flies during this tile's MFMAs as before.
 #pragma once
+#include <type_traits>
 #include "pcv_common.hpp"
 #include "igemm_conv.hpp"     // Mma<DT>
 
@@ -115,6 +116,22 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         prow[j] = c / PCH;
         pcol[j] = c - prow[j] * PCH;
     }
+    // NCHW staging: chunk c = 256 j + tid -> (plane, patch row, column chunk) does not depend on the tile: its decomposition (two divisions by
+    // constants per chunk) is done once, a tile adds its origin and checks the image border
+    int srow[NCHW ? 5 : 1], scol[NCHW ? 5 : 1], soff[NCHW ? 5 : 1];
+    uint32_t sok = 0;                                         // bit j: plane and patch row of chunk j exist
+    if constexpr (NCHW) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int c = 256 * j + tid;
+            const int pl = c / (11 * 37), rem = c - pl * (11 * 37);
+            const int r = rem / 11, cc = rem - r * 11;
+            srow[j] = r;
+            scol[j] = 4 * cc;
+            soff[j] = ((pl * p.H + r) * p.W + 4 * cc) * 4;
+            sok |= (pl < p.Cin && r < PR ? 1u : 0u) << j;
+        }
+    }
     auto issue_patch = [&](int t, int buf) {
         const int tw = t % p.tilesW;
         const int t2 = t / p.tilesW;
@@ -125,14 +142,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
         if constexpr (NCHW) {
             // chunk c = 256 j + tid -> (plane, patch row, column chunk); source column = 4-aligned origin at or below wp0
             const int wa = wp0 & ~3;
+            const int base = ((n * p.Cin * p.H + hi0) * p.W + wa) * 4;       // (plane 0, patch row 0, column chunk 0) of this tile
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                const int c = 256 * j + tid;
-                const int pl = c / (SFC * 37), rem = c - pl * (SFC * 37);
-                const int r = rem / SFC, cc = rem - r * SFC;
-                const int hi = hi0 + r, wc0 = wa + 4 * cc;
-                const bool ok = pl < p.Cin && r < PR && (unsigned)hi < (unsigned)p.H && (unsigned)wc0 < (unsigned)p.W;
-                const uint32_t off = ok ? (uint32_t)((((n * p.Cin + pl) * p.H + hi) * p.W + wc0) * 4) : 0x80000000u;
+                const bool ok = ((sok >> j) & 1u) != 0 && (unsigned)(hi0 + srow[j]) < (unsigned)p.H && (unsigned)(wa + scol[j]) < (unsigned)p.W;
+                const uint32_t off = ok ? (uint32_t)(base + soff[j]) : 0x80000000u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, PCV_LDS(stage + (256 * j + (tid & ~63)) * 16), 16, off, 0, 0, 0);
             }
             return;
@@ -221,18 +235,39 @@ __global__ __launch_bounds__(256, 2) void stem_conv_kernel(const StemParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const char* pbase = smem + WBYTES + (NCHW ? 0 : buf) * PBYTES + xfrag;
-        for (int r = 0; r < p.kh; ++r) {
-            frag a[CB], b[4];
+        auto load_row = [&](int r, frag (&a)[CB], frag (&b)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < CB; ++i) a[i] = *reinterpret_cast<const frag*>(smem + r * 4096 + i * 1024 + wfrag);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 b[j] = *reinterpret_cast<const frag*>(pbase + (2 * (4 * wave + j) + r) * (PCH * 16));
+        };
+        // The usual filter heights (7: ResNet-style stems, 3: MobileNet / EfficientNet) as compile-time loops with the next row's fragments
+        // requested in front of this row's MFMAs; with a run-time trip count every row waited for its own eight LDS reads.
+        auto rows = [&](auto KHc) __attribute__((always_inline)) {
+            constexpr int KH = decltype(KHc)::value;
+            frag a[2][CB], b[2][4];
+            load_row(0, a[0], b[0]);
 #pragma unroll
-            for (int i = 0; i < CB; ++i)
+            for (int r = 0; r < KH; ++r) {
+                if (r + 1 < KH) load_row(r + 1, a[(r + 1) & 1], b[(r + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
-        }
+                for (int i = 0; i < CB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a[r & 1][i], b[r & 1][j], acc[i][j]);
+            }
+        };
+        if (p.kh == 7) rows(std::integral_constant<int, 7>{});
+        else if (p.kh == 3) rows(std::integral_constant<int, 3>{});
+        else
+            for (int r = 0; r < p.kh; ++r) {
+                frag a[CB], b[4];
+                load_row(r, a, b);
+#pragma unroll
+                for (int i = 0; i < CB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mma<DT>::run(a[i], b[j], acc[i][j]);
+            }
 
         // ---- epilogue: BN + activation, 16-byte NHWC stores (range-checked: tile tails and channel padding drop) ------------
         const int tw = tile % p.tilesW;
