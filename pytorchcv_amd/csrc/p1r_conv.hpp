@@ -26,9 +26,6 @@
 #include "igemm_conv.hpp"     // Mma<DT>
 #include "d3q_conv.hpp"       // D3Params, D3Tiles, d3q_tiles
 
-#ifndef P1R_STORE_AUX
-#define P1R_STORE_AUX 0
-#endif
 template <int CW_, int CIN_>
 struct P1RCfg {
     static constexpr int CW = CW_;                           // channels per wave
@@ -202,7 +199,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
     // range check drops it (y_bytes / res_bytes are exact).
     uint32_t yb[CWB / 2], rb[CWB / 2];
     auto epi_store = [&](int u, int ip) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b128(opend, yrsrc, yb[ip] + (uint32_t)(u * 32 * p.Ypitch), 0, P1R_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(opend, yrsrc, yb[ip] + (uint32_t)(u * 32 * p.Ypitch), 0, 0);      // (nt / sc1 stores measured: no difference)
     };
     // one tile: 64 steps (unit u, K-half kh); the wave's 8 pieces of the NEXT tile go out during unit 0 (into the other slot: every
     // wave left it before the barrier that ended the last tile), so that every store of this tile is issued behind them
