@@ -65,6 +65,7 @@ struct D3Params {
     int stride, Hin, Win;   // 1x1 mode only: output pixel (n, ho, wo) reads input pixel (n, stride ho, stride wo) of an Hin x Win map
                             // (H, W, HW, div_hw, div_w then describe the OUTPUT map)
     uint32_t* ovf;          // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
+    int tailN;              // p1r_conv.hpp only: tiles nTiles .. nTiles + tailN - 1 are split into 16-pixel units over the blocks (0: none)
     int dbgflags;           // timing experiments only (pcv_set_tuning("dbg", bits); results are WRONG with any bit set): 1 = output stores
                             // dropped (out-of-range offsets), 2 = no epilogue at all, 4 = loaders keep the first tile's row table, 8 = compute waves keep the
                             // first tile's column masks, 16 = row table built at the tile change (A/B of the look-ahead build; results stay right)

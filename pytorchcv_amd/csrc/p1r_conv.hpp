@@ -110,6 +110,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
     const uint32_t lanesrc = (uint32_t)((((lane & 7) ^ lrow) << 4));
     int tileP0N = 0;                                              // first output pixel of the NEXT tile (or of the first, in the prologue)
     bool moreN = false;
+    bool pseudoN = false;                                         // the next "tile" is one 16-pixel unit of a split tail tile: only its unit 0 exists
     uint32_t pixoff = 0x80000000u;                                // byte offset of this lane's input pixel of the unit being staged
     auto unit_src = [&](int unit) __attribute__((always_inline)) {
         const int m = tileP0N + unit * 16 + half8 * 8 + lrow;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
             const uint32_t wo = rem - ho * (uint32_t)p.W;
             mi = (n * (uint32_t)p.Hin + ho * (uint32_t)p.stride) * (uint32_t)p.Win + wo * (uint32_t)p.stride;
         }
-        pixoff = (moreN && m < p.M) ? mi * (uint32_t)(G::CIN * 2) + lanesrc : 0x80000000u;       // (the host keeps x below 2 GiB)
+        pixoff = (moreN && m < p.M && !(pseudoN && unit > 0)) ? mi * (uint32_t)(G::CIN * 2) + lanesrc : 0x80000000u;       // (the host keeps x below 2 GiB)
     };
     auto dma_piece = [&](auto Ic, int slot) __attribute__((always_inline)) {
         constexpr int I = decltype(Ic)::value;
@@ -203,7 +204,10 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
     };
     // one tile: 64 steps (unit u, K-half kh); the wave's 8 pieces of the NEXT tile go out during unit 0 (into the other slot: every
     // wave left it before the barrier that ended the last tile), so that every store of this tile is issued behind them
-    auto tile_steps = [&](auto HRc, int slot, int ch0, int mTile) __attribute__((always_inline)) {
+    // ONE: a single-unit pseudo tile - unit 0's steps, then its epilogue on its own (its own instantiation: as a run-time branch inside the
+    // full tile's code it cost that code 20 registers it does not have)
+    auto tile_steps = [&](auto HRc, auto ONEc, int slot, int ch0, int mTile) __attribute__((always_inline)) {
+        constexpr bool ONE = decltype(ONEc)::value;
         constexpr bool HR = (decltype(HRc)::value & 1) != 0;
         F16Guard<DT> guard;
 #pragma unroll
@@ -215,7 +219,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
         if constexpr (HR) {
             // the skip tensor's pieces of the whole tile, in FRONT of the LDS-DMA pieces (vmcnt retires in order)
 #pragma unroll
-            for (int u = 0; u < TP; ++u)
+            for (int u = 0; u < (ONE ? 1 : TP); ++u)
 #pragma unroll
                 for (int ip = 0; ip < CWB / 2; ++ip) {
                     rrq[(u * (CWB / 2) + ip) % NRR] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rb[ip] + (uint32_t)(u * 32 * p.Cout), 0, 0);
@@ -268,21 +272,29 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
                 std::integral_constant<int, B0 + 3>{}, std::integral_constant<int, B0 + 4>{}, std::integral_constant<int, B0 + 5>{},
                 std::integral_constant<int, B0 + 6>{}, std::integral_constant<int, B0 + 7>{});
         };
-        eight(std::integral_constant<int, 0>{}); eight(std::integral_constant<int, 1>{}); eight(std::integral_constant<int, 2>{});
-        eight(std::integral_constant<int, 3>{}); eight(std::integral_constant<int, 4>{}); eight(std::integral_constant<int, 5>{});
-        eight(std::integral_constant<int, 6>{}); eight(std::integral_constant<int, 7>{});
-        {                                                           // the last unit's epilogue: on its own
-            typedef std::integral_constant<int, TP - 1> UL;
+        auto last_epilogue = [&](auto ULc) __attribute__((always_inline)) {       // a unit's epilogue on its own (nothing left to hide it under)
+            typedef decltype(ULc) UL;
+            constexpr int ul = UL::value;
             ss_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); ss_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             epi_part(HRc, UL{}, std::integral_constant<int, 0>{}, guard); epi_part(HRc, UL{}, std::integral_constant<int, 1>{}, guard);
             epi_part(HRc, UL{}, std::integral_constant<int, 2>{}, guard); epi_part(HRc, UL{}, std::integral_constant<int, 3>{}, guard);
-            epi_store(TP - 1, 0);
+            epi_store(ul, 0);
             if constexpr (CWB == 4) {
                 ss_read(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); ss_read(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
                 epi_part(HRc, UL{}, std::integral_constant<int, 4>{}, guard); epi_part(HRc, UL{}, std::integral_constant<int, 5>{}, guard);
                 epi_part(HRc, UL{}, std::integral_constant<int, 6>{}, guard); epi_part(HRc, UL{}, std::integral_constant<int, 7>{}, guard);
-                epi_store(TP - 1, 1);
+                epi_store(ul, 1);
             }
+        };
+        eight(std::integral_constant<int, 0>{});
+        if constexpr (KH == 16) eight(std::integral_constant<int, 1>{});
+        if constexpr (ONE) last_epilogue(std::integral_constant<int, 0>{});
+        else {
+            if constexpr (KH == 8) eight(std::integral_constant<int, 1>{});
+            eight(std::integral_constant<int, 2>{});
+            eight(std::integral_constant<int, 3>{}); eight(std::integral_constant<int, 4>{}); eight(std::integral_constant<int, 5>{});
+            eight(std::integral_constant<int, 6>{}); eight(std::integral_constant<int, 7>{});
+            last_epilogue(std::integral_constant<int, TP - 1>{});
         }
         guard.commit(p.ovf);
     };
@@ -302,6 +314,16 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
         eight(std::integral_constant<int, 0>{});
     }
 
+    // The tail: when the tile count is not a multiple of the grid, the host splits the last (partial) round's tiles into their 16-pixel
+    // units, one per block - a block's unit belongs to a tile of ITS channel group (block j of an XCD owns group j % nCG; the r-th block
+    // of a group takes unit r % TP of the group's tail tile r / TP). It runs as a one-unit pseudo tile behind the block's last tile.
+    int tailP0 = -1;
+    if (p.tailN > 0) {
+        const int nCG = p.nChTiles, B = gridDim.x >> 3, j = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+        const int r = xcd * (B / nCG) + j / nCG, k = r / TP, u = r - k * TP;
+        if (k < p.tailN / nCG) tailP0 = (p.nTiles / nCG + k) * G::BP + 16 * u;
+    }
+    bool pseudo = false;
     int slot = 0, t = T.tile0;
     // a RUN of tiles that share their channel group: weights and BN constants are loaded in front of the run (d3c_conv.hpp)
     while (t < T.tend) {
@@ -328,8 +350,10 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
         do {
             const int tn = t + T.tstride;
             moreN = tn < T.tend;
-            const int cgN = moreN ? tn % p.nChTiles : cg;
+            int cgN = moreN ? tn % p.nChTiles : cg;
             tileP0N = moreN ? (tn / p.nChTiles) * G::BP : 0;
+            pseudoN = !moreN && !pseudo && tailP0 >= 0;          // behind the last tile: this block's unit of the split tail
+            if (pseudoN) { moreN = true; cgN = cg; tileP0N = tailP0; }
             fs0 = fbase + (uint32_t)(slot * G::SLOT);
             fs1 = fs0 ^ 64u;
 #ifdef P1R_CYCLES      // diagnostic build (tests/tools/p1r_cycles.py): shader-cycle stamps of this block's third tile
@@ -342,16 +366,20 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
                 const int ch0 = cg * G::CG + wave * CW + 8 * fq;
                 // (uniform branches; MODE bits: epi_part)
                 const bool hi = p.act == PCV_ACT_RELU6 || p.post_act == PCV_ACT_RELU6, pre = p.act != PCV_ACT_NONE;
-                if constexpr (G::RES) {
-                    if (has_res) {
-                        if (!hi && !pre) tile_steps(std::integral_constant<int, 1>{}, slot, ch0, tileP0);
-                        else tile_steps(std::integral_constant<int, 7>{}, slot, ch0, tileP0);
-                    } else if (!hi) tile_steps(std::integral_constant<int, 0>{}, slot, ch0, tileP0);
-                    else tile_steps(std::integral_constant<int, 4>{}, slot, ch0, tileP0);
-                } else {
-                    if (!hi) tile_steps(std::integral_constant<int, 0>{}, slot, ch0, tileP0);
-                    else tile_steps(std::integral_constant<int, 4>{}, slot, ch0, tileP0);
-                }
+                auto modes = [&](auto ONEc) __attribute__((always_inline)) {
+                    if constexpr (G::RES) {
+                        if (has_res) {
+                            if (!hi && !pre) tile_steps(std::integral_constant<int, 1>{}, ONEc, slot, ch0, tileP0);
+                            else tile_steps(std::integral_constant<int, 7>{}, ONEc, slot, ch0, tileP0);
+                        } else if (!hi) tile_steps(std::integral_constant<int, 0>{}, ONEc, slot, ch0, tileP0);
+                        else tile_steps(std::integral_constant<int, 4>{}, ONEc, slot, ch0, tileP0);
+                    } else {
+                        if (!hi) tile_steps(std::integral_constant<int, 0>{}, ONEc, slot, ch0, tileP0);
+                        else tile_steps(std::integral_constant<int, 4>{}, ONEc, slot, ch0, tileP0);
+                    }
+                };
+                if (pseudo) modes(std::true_type{});
+                else modes(std::false_type{});
             }
 #ifdef P1R_CYCLES
             if (stamp__) c1__ = __builtin_amdgcn_s_memtime();
@@ -378,10 +406,12 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
 #endif
             same = moreN && cgN == cg;
             cg = cgN; tileP0 = tileP0N;
+            pseudo = pseudoN;
             slot ^= 1;
             t = tn;
         } while (same);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (a pseudo tile's out-of-range DMA pieces: nothing may land in LDS after the block has left)
 }
 #endif  // __HIP_DEVICE_COMPILE__
 

@@ -66,8 +66,8 @@ struct pcv_ctx {
     int use_d3x3 = -1;          // 8-wave dense 3x3 kernel (d3x3_conv.hpp): -1 = where eligible (16-bit, s1/p1, Cin % 64 == 0) with the tile shape
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
-    int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
-    int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
+    int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
+    int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
     int dw_flags = 0;           // tuning: bit 0 = non-temporal stores in the depthwise kernels
@@ -1404,6 +1404,16 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     const long long slots = block_slots(ctx, 1);
     long long nb = slots < nT ? slots : nT;
     nb = (nb + 7) / 8 * 8;
+    if (p1r && nT > nb) {
+        // p1r: equal tiles on a persistent grid leave the last round partly empty (12.25 rounds = 13). When the remainder splits evenly -
+        // its tiles into 16-pixel units, one per block, every block getting a unit of its own channel group - the kernel runs it as
+        // one-unit pseudo tiles behind the full rounds (p1r_conv.hpp, `tailN`).
+        const long long nCG = q.nChTiles, TP = S.BP / 16, rem = nT % nb;
+        if (rem > 0 && nb % (8 * nCG) == 0 && rem % nCG == 0 && rem * TP <= nb && ctx->use_p1r != 3 && ctx->use_p1r != -3) {        // ("p1r" = 3 / -3: forced / automatic routing without the split tail, for A/B)
+            q.nTiles = (int)(nT - rem);
+            q.tailN = (int)rem;
+        }
+    }
     void* args[] = {&q};
     HIP_TRY(ctx, hipLaunchKernel(S.fn[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nb), dim3(c64 ? 256 : ((wide || p1r) ? 512 : 768)), args, (size_t)S.lds, A.stream));
     return PCV_OK;

@@ -660,6 +660,9 @@ _P1R_SHAPES = [  # (N, Cin, Cout, H, W, residual, stride): 256 / 512 input chann
     (4, 512, 1024, 14, 14, True, 1), (3, 512, 2048, 7, 7, True, 1), (2, 512, 256, 28, 28, False, 2), (2, 512, 1024, 28, 28, False, 2),
     (2, 256, 512, 56, 56, False, 2), (3, 256, 512, 13, 11, False, 1), (2, 256, 600, 9, 7, False, 2), (1, 512, 136, 5, 9, True, 1),
     (1, 512, 520, 1, 1, False, 1), (5, 256, 1024, 14, 14, True, 1), (2, 512, 512, 17, 5, False, 2),
+    # the split tail round (a tile count one or two beyond a multiple of the grid, one channel group: 9 tiles of 128 / 17 and 18 of 64
+    # pixels on the 8-block grid; on the resident grid these are ordinary single rounds), with a partial last unit
+    (9, 256, 512, 11, 11, False, 1), (17, 512, 256, 8, 8, True, 1), (2, 512, 256, 24, 24, False, 1), (9, 256, 264, 11, 12, False, 1),
 ]
 
 
