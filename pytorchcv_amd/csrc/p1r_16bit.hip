@@ -5,3 +5,4 @@
     template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
 P1R_INST(64, 256)
 P1R_INST(32, 512)
+P1R_INST(32, 256)

@@ -32,13 +32,13 @@ struct P1RCfg {
     static constexpr int CIN = CIN_;
     static constexpr int CWB = CW / 16;                      // 16-row MFMA blocks per wave
     static constexpr int KH = CIN / 32;                      // K-halves (one MFMA deep each)
-    static constexpr int AREGS = CWB * KH * 4;               // registers per lane that hold the wave's weights: 128
+    static constexpr int AREGS = CWB * KH * 4;               // registers per lane that hold the wave's weights: 128 (32 x 256: 64)
     static constexpr int NW = 8;                             // waves, two per SIMD (256 registers each). (Four waves of 64 channels x 512 with
                                                              // 256 weight registers: the compiler parks half of them in AGPRs and copies
                                                              // them back per use - 84 us where the eight-wave form takes 75, and no partner
                                                              // wave for the epilogue: measured and dropped.)
     static constexpr int THREADS = 64 * NW;
-    static constexpr int CG = NW * CW;                       // channels per block: 512 / 256
+    static constexpr int CG = NW * CW;                       // channels per block: 512 / 256 / 256
     static constexpr int BM = CG;
     static constexpr int UNITB = 16 * CIN * 2;               // one 16-pixel unit: 8 / 16 KB
     static constexpr int SLOT = 65536;
@@ -50,8 +50,8 @@ struct P1RCfg {
     static constexpr int LDS = SSOFF + 2 * CG * 4;
     static constexpr int NSTEP = TP * KH;                    // 64
     static constexpr int NSTORE = TP * (CWB / 2);            // 16-byte stores per lane per tile (all issued behind the tile's DMA pieces)
-    static constexpr bool RES = CIN == 512;                  // a skip tensor's pieces of a whole tile fit the registers (4 x 16 bytes per lane)
-    static_assert((CW == 64 && CIN == 256) || (CW == 32 && CIN == 512), "two configurations");
+    static constexpr bool RES = CW == 32;                    // a skip tensor's pieces of a whole tile fit the registers (4 / 8 x 16 bytes per lane)
+    static_assert((CW == 64 && CIN == 256) || (CW == 32 && CIN == 512) || (CW == 32 && CIN == 256), "three configurations");
     static_assert(NSTEP == 64 && TP * PPU == 64 && PPU % NW == 0 && KH % NPW == 0, "tile geometry");
 };
 
@@ -147,7 +147,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
     const float alo = (p.act == PCV_ACT_RELU || p.act == PCV_ACT_RELU6) ? 0.f : -INFINITY, ahi = p.act == PCV_ACT_RELU6 ? 6.f : INFINITY;
     const float plo = (p.post_act == PCV_ACT_RELU || p.post_act == PCV_ACT_RELU6) ? 0.f : -INFINITY, phi = p.post_act == PCV_ACT_RELU6 ? 6.f : INFINITY;
     const float clo = alo > plo ? alo : plo, chi = ahi < phi ? ahi : phi;
-    constexpr int NRR = G::RES ? TP * (CWB / 2) : 1;              // residual pieces of a tile (512 input channels only: 4)
+    constexpr int NRR = G::RES ? TP * (CWB / 2) : 1;              // residual pieces of a tile (32 channels per wave only: 4 / 8)
     u32x4 rrq[NRR];
     u32x4 opend;
     // BN constants of (32-channel group ip, accumulator half): two buffers (half 0 / 1), read from the wave's LDS strip at least a step
@@ -255,6 +255,13 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
                     if constexpr (kh == 5) { part(I4{}); part(I5{}); }
                     if constexpr (kh == 6) { part(I6{}); part(I7{}); }
                     if constexpr (kh == 7) epi_store(u - 1, 1);
+                } else if constexpr (KH == 8) {                     // 4 parts + 1 store over 8 steps
+                    if constexpr (kh == 0) { ss_read(I0{}, I0{}); ss_read(I0{}, I1{}); }
+                    if constexpr (kh == 2) part(I0{});
+                    if constexpr (kh == 3) part(I1{});
+                    if constexpr (kh == 5) part(I2{});
+                    if constexpr (kh == 6) part(I3{});
+                    if constexpr (kh == 7) epi_store(u - 1, 0);
                 } else {                                            // 4 parts + 1 store over 16 steps
                     if constexpr (kh == 0) { ss_read(I0{}, I0{}); ss_read(I0{}, I1{}); }
                     if constexpr (kh == 3) part(I0{});
@@ -386,6 +393,7 @@ __device__ __forceinline__ void p1r_body(const D3Params& p, char* smem) {
 #endif
             // the next tile has landed (behind its pieces only this tile's NSTORE stores were issued); every wave is done with this one
             if constexpr (G::NSTORE == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if constexpr (G::NSTORE == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 #ifdef P1R_CYCLES
             if (stamp__) c2__ = __builtin_amdgcn_s_memtime();

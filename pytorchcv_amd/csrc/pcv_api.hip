@@ -50,6 +50,7 @@ extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
     extern template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
 P1R_DECLARE(64, 256)
 P1R_DECLARE(32, 512)
+P1R_DECLARE(32, 256)
 
 struct pcv_ctx {
     int device = 0;
@@ -455,13 +456,14 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
-// p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels)
+// p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels), [2] 256 input channels with
+// 32 channels per wave (a skip tensor, or fewer than 384 output channels)
 #define P1R_ROW(CW, CIN)                                                                   \
     {P1RCfg<CW, CIN>::BM, P1RCfg<CW, CIN>::BP, P1RCfg<CW, CIN>::LDS,                       \
      {reinterpret_cast<const void*>(p1r_kernel<PCV_BF16, CW, CIN>), reinterpret_cast<const void*>(p1r_kernel<PCV_F16, CW, CIN>)}}
-static const D3Shape kP1R[2] = {P1R_ROW(64, 256), P1R_ROW(32, 512)};
+static const D3Shape kP1R[3] = {P1R_ROW(64, 256), P1R_ROW(32, 512), P1R_ROW(32, 256)};
 static int enable_d3x3(pcv_ctx* ctx) {
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int i = 0; i < kD3WCount; ++i)
@@ -1233,10 +1235,11 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
         G.cpitch == d->Cin && G.wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && clamp_acts && A.scale && A.shift &&
         G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
         // 256 / 512 input channels: the kernel that keeps the weights in registers, where its tiles fill the chip and (almost) every
-        // wave of a channel group has channels to compute; a skip tensor only in the 512-channel form (register budget)
-        if (ctx->use_p1r != 0 && (ctx->use_d1x1 < 0 || ctx->use_p1r > 0) && (d->Cin == 256 || d->Cin == 512) && G.xbytes < 0x80000000ull &&
-            !(d->Cin == 256 && d->has_residual)) {
-            const int shape = d->Cin == 256 ? 0 : 1;
+        // wave of a channel group has channels to compute
+        if (ctx->use_p1r != 0 && (ctx->use_d1x1 < 0 || ctx->use_p1r > 0) && (d->Cin == 256 || d->Cin == 512) && G.xbytes < 0x80000000ull) {
+            // 256 input channels: 64 channels per wave (groups of 512) unless the layer has a skip tensor (whose pieces only fit beside 32
+            // channels' weights) or too few channels for 3/4 of such a group
+            const int shape = d->Cin == 512 ? 1 : ((d->has_residual || d->Cout < 384) ? 2 : 0);
             const D3Shape& S = kP1R[shape];
             const long long groups = (d->Cout + S.BM - 1) / S.BM, tiles = ((long long)G.M64 + S.BP - 1) / S.BP * groups;
             if (ctx->use_p1r > 0 || (d->Cout * 4 >= groups * S.BM * 3 && tiles >= 2ll * block_slots(ctx, 1))) {

@@ -663,6 +663,8 @@ _P1R_SHAPES = [  # (N, Cin, Cout, H, W, residual, stride): 256 / 512 input chann
     # the split tail round (a tile count one or two beyond a multiple of the grid, one channel group: 9 tiles of 128 / 17 and 18 of 64
     # pixels on the 8-block grid; on the resident grid these are ordinary single rounds), with a partial last unit
     (9, 256, 512, 11, 11, False, 1), (17, 512, 256, 8, 8, True, 1), (2, 512, 256, 24, 24, False, 1), (9, 256, 264, 11, 12, False, 1),
+    # 256 input channels with 32 channels per wave (a skip tensor, or fewer than 384 output channels): ragged groups, stride 2, a split tail
+    (3, 256, 256, 20, 20, False, 1), (2, 256, 128, 9, 9, False, 2), (2, 256, 264, 11, 12, True, 1), (9, 256, 256, 11, 11, True, 1),
 ]
 
 
@@ -673,8 +675,8 @@ def test_conv1x1_register_weights_kernel_equals_generic_and_oracle(shape, dtype,
     """p1r_kernel (1x1 with 256 / 512 input channels: ResBottleneck.conv3 / ResNeXtBottleneck.conv3 and the strided identity
     convolutions, reference resnet.py:128-131,200-206, resnext.py:63-66,107-113): bit-identical to the generic implicit GEMM (same K
     order, same MFMA chain per accumulator) on whole and partial pixel tiles, several channel groups (weights reloaded per run of
-    tiles), ragged channel counts, stride 1 and 2, with and without the residual epilogue (256 channels + residual: another kernel
-    takes the layer - still equal); and within the 16-bit bound of the quantisation-matched oracle."""
+    tiles), ragged channel counts, stride 1 and 2, with and without the residual epilogue, all three forms (64 / 32 channels per wave at 256
+    input channels, 32 at 512); and within the 16-bit bound of the quantisation-matched oracle."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv1x1_block
