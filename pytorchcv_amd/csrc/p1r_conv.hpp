@@ -13,12 +13,14 @@
 // cycles (34 B/clk per CU where ~16 arrive next to a running matrix pipe, profiles/experiments/r04_d3w_loop.md), and with K = 256
 // or 512 a tile is only 4-8 K-steps long, so its epilogue (up to 51 of 110 us on the 256 -> 512 stride-2 layer) is never hidden.
 // Here:
-//   * a block owns a channel GROUP of 8 x CW channels (CW = 64 with 256 input channels, 32 with 512): wave w holds the CW x Cin
-//     weights of its channels as MFMA A fragments - 128 registers per lane, two waves per SIMD - loaded once per run of tiles;
+//   * a block owns a channel GROUP of 8 x CW channels (CW = 64 with 256 input channels, 32 with 512; a third form, 32 x 256, for the
+//     256-channel layers with a skip tensor or fewer than 384 output channels): wave w holds the CW x Cin weights of its channels as MFMA A
+//     fragments - 128 (64) registers per lane, two waves per SIMD - loaded once per run of tiles;
 //   * a tile is 64 KB of activations (128 or 64 pixels, all input channels) staged ONCE by LDS-DMA: 8-16 B/clk per CU; every
 //     wave reads every fragment (one ds_read_b128 per 4 or 2 MFMAs);
 //   * pixel-block-outer K loop (d3c_conv.hpp): a 16-pixel unit runs through all K-halves, then its BN / activation / residual /
-//     store parts are written between the MFMAs of the next unit; two tile slots, ONE barrier per tile.
+//     store parts are written between the MFMAs of the next unit; two tile slots, ONE barrier per tile;
+//   * the partial last round of a persistent grid is split into its 16-pixel units, one per block (`tailN`, below).
 // LDS image of a unit (16 pixels): [64-channel slice][16 rows x 128 B], 16-byte chunk slot s of row R holds K-chunk s ^ (R & 7).
 #pragma once
 #include <type_traits>
