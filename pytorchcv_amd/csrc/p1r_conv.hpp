@@ -36,9 +36,12 @@ struct P1RCfg {
     static constexpr int KH = CIN / 32;                      // K-halves (one MFMA deep each)
     static constexpr int AREGS = CWB * KH * 4;               // registers per lane that hold the wave's weights: 128 (32 x 256: 64)
     static constexpr int NW = 8;                             // waves, two per SIMD (256 registers each). (Four waves of 64 channels x 512 with
-                                                             // 256 weight registers: the compiler parks half of them in AGPRs and copies
-                                                             // them back per use - 84 us where the eight-wave form takes 75, and no partner
-                                                             // wave for the epilogue: measured and dropped.)
+                                                             // 256 weight registers, one per SIMD, half the LDS fragment reads: measured twice
+                                                             // and dropped. With the compiler's MFMAs it parks half of the weights in AGPRs and
+                                                             // copies them back per use: 84 us where this form takes 75. With inline-asm MFMAs
+                                                             // whose A operand is constrained to "a" - 256 AGPRs of weights, no copy, no spill,
+                                                             // bit-identical - 85 against 78, 48.5 against 44.6 at 7x7: a wave alone on its SIMD
+                                                             // has no partner to cover its epilogue and memory waits.)
     static constexpr int THREADS = 64 * NW;
     static constexpr int CG = NW * CW;                       // channels per block: 512 / 256 / 256
     static constexpr int BM = CG;
