@@ -60,7 +60,7 @@ CLASS_BOUND = {"dense3x3": "mfma", "dense1x1_kheavy": "mfma"}           # everyt
 def kernel_class_of(name: str):
     """Kernel class of a rocprofv3 kernel name, None for kernels outside the convolution path (pools, head, layout, torch)."""
     head = name.split("(")[0].rstrip()
-    if "d3w_kernel" in name or "d3c_kernel" in name:
+    if "d3w_kernel" in name or "d3c_kernel" in name or "d3k_kernel" in name:
         return "dense3x3"
     if "p1r_kernel" in name:
         return "dense1x1_kheavy"

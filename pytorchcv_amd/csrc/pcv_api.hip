@@ -13,6 +13,7 @@
 #include "d3q_inst.hpp"
 #include "d3w_inst.hpp"
 #include "d3c_conv.hpp"
+#include "d3k_conv.hpp"
 #include "p1r_conv.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
@@ -45,6 +46,8 @@ D3WT_SHAPES(D3WT_DECLARE, PCV_BF16)
 D3WT_SHAPES(D3WT_DECLARE, PCV_F16)
 extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
+extern template __global__ void d3k_kernel<PCV_BF16>(const D3Params);
+extern template __global__ void d3k_kernel<PCV_F16>(const D3Params);
 #define P1R_DECLARE(CW, CIN)                                                       \
     extern template __global__ void p1r_kernel<PCV_BF16, CW, CIN>(const D3Params); \
     extern template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
@@ -68,6 +71,7 @@ struct pcv_ctx {
                                 // the cost model picks, 0 = never, n > 0 = always with tile shape n - 1 (tests / sweeps)
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
     int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
+    int use_d3k = -1;           // 128-input-channel dense 3x3 kernel on 28-wide maps (d3k_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
     int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
@@ -456,6 +460,7 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
+static const void* kD3K[2] = {reinterpret_cast<const void*>(d3k_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3k_kernel<PCV_F16>)};
 // p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels), [2] 256 input channels with
 // 32 channels per wave (a skip tensor, or fewer than 384 output channels)
 #define P1R_ROW(CW, CIN)                                                                   \
@@ -466,6 +471,7 @@ static int enable_d3x3(pcv_ctx* ctx) {
     for (int i = 0; i < 3; ++i)
         for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
+    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3K[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3KCfg::LDS));
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
@@ -840,6 +846,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d3x3") ctx->use_d3x3 = value;
     else if (k == "d3w") ctx->use_d3w = value;
     else if (k == "d3c") ctx->use_d3c = value;
+    else if (k == "d3k") ctx->use_d3k = value;
     else if (k == "p1r") ctx->use_p1r = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "stem32") ctx->use_stem32 = value;
@@ -1137,6 +1144,7 @@ enum ConvKernel {
     CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
+    CK_D3K,         // d3k_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 128 input channels on 28-wide maps (weights in registers / AGPRs)
     CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
     CK_D3Q,         // d3q_conv.hpp: dense 3x3 / s1 / p1, 16 bit
@@ -1222,6 +1230,12 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
             d->W == D3CCfg::W && G.cpitch == d->Cin && G.wpitch == d->W) {
             const long long tiles = (long long)((d->Cout + 63) / 64) * d->N * ((d->H + D3CCfg::ROWS - 1) / D3CCfg::ROWS);
             if (ctx->use_d3c > 0 || tiles >= 2ll * block_slots(ctx, 1)) { R.kernel = CK_D3C; return R; }
+        }
+        // 128 input channels on a 28-wide map (ResNet stage 2): 4-row tiles of one image per 128-channel tile, from two tiles per CU up
+        if (ctx->use_d3k != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3k > 0) && (ctx->use_d3w <= 0 || ctx->use_d3k > 0) && d->Cin == D3KCfg::CIN &&
+            d->W == D3KCfg::W && G.cpitch == d->Cin && G.wpitch == d->W) {
+            const long long tiles = (long long)((d->Cout + D3KCfg::BM - 1) / D3KCfg::BM) * d->N * ((d->H + D3KCfg::ROWS - 1) / D3KCfg::ROWS);
+            if (ctx->use_d3k > 0 || tiles >= 2ll * block_slots(ctx, 1)) { R.kernel = CK_D3K; return R; }
         }
         if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
             R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
@@ -1375,9 +1389,10 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     if (ybytes >= 0x80000000ull)
         return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
     static const D3Shape kC64 = {D3CCfg::BM, D3CCfg::BP, D3CCfg::LDS, {kD3C[0], kD3C[1]}};
+    static const D3Shape kC128 = {D3KCfg::BM, D3KCfg::BP, D3KCfg::LDS, {kD3K[0], kD3K[1]}};      // (c64 with shape 1: d3k_kernel, the same tile scheme)
     // wide: d3w_kernel (512 threads); c64: d3c_kernel (256 threads, tiles = 4 output rows of one image); same parameter block
     // p1r: p1r_kernel (512 threads; 1x1 mode of the parameter block, channel "tiles" = groups of 512 / 256 channels)
-    const D3Shape& S = p1r ? kP1R[shape] : (c64 ? kC64 : (wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape])));
+    const D3Shape& S = p1r ? kP1R[shape] : (c64 ? (shape == 1 ? kC128 : kC64) : (wide ? kD3W[shape] : (one ? kD1[shape] : kD3[shape])));
     D3Params q;
     std::memset(&q, 0, sizeof(q));
     q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.ktab_bytes; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
@@ -1559,6 +1574,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         case CK_GCONV_ROWS: return launch_gconv_rows(ctx, d, P, G, A, R.rows);
         case CK_GCONV_FLAT: return launch_gconv_flat(ctx, d, P, G, A);
         case CK_D3C: return launch_d3q(ctx, d, P, G, A, 0, false, false, true);
+        case CK_D3K: return launch_d3q(ctx, d, P, G, A, 1, false, false, true);
         case CK_D3W: return launch_d3q(ctx, d, P, G, A, R.shape, false, true);
         case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
         case CK_P1R: return launch_d3q(ctx, d, P, G, A, R.shape, true, false, false, true);

@@ -618,6 +618,46 @@ def test_conv3x3_c64_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_d
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
+_D3K_SHAPES = [  # (N, Cout, H, residual): 128 input channels on 28-wide maps (csrc/d3k_conv.hpp: weights in registers / AGPRs, 4-row tiles)
+    (2, 128, 28, False), (3, 128, 28, True), (2, 256, 30, False), (1, 192, 5, True), (5, 136, 9, True), (1, 128, 1, False), (40, 128, 4, True),
+]
+
+
+@pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _D3K_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D3K_SHAPES])
+def test_conv3x3_c128_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_device):
+    """d3k_kernel (128 input channels, 28-wide maps: ResNet stage 2, reference resnet.py:49,56,120-127): bit-identical to the generic
+    implicit GEMM (same K order, same MFMA chain per accumulator - its MFMAs are inline asm with the weights in AGPRs) on whole and partial
+    row tiles (H % 4 != 0), several / ragged channel tiles (weights reloaded per run of tiles), with and without the residual epilogue; and
+    within the 16-bit bound of the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, Cout, H, use_res = shape
+    C, W = 128, 28
+    blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=79)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=25)
+    res = util.synth_input(N, Cout, H, W, seed=26) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        with util.tuning(max_blocks=grid, d3k=1):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        with util.tuning(d3x3=0):
+            yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        assert torch.equal(yh.t, yg.t), "d3k differs from the generic implicit GEMM in {} elements".format(int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
 _D1_SHAPES = [  # (N, Cin, Cout, H, W, residual[, stride]): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
     (16, 1024, 512, 14, 14, False), (16, 512, 1024, 14, 14, True), (9, 2048, 512, 7, 7, False), (5, 512, 2048, 7, 7, True),
     (3, 576, 136, 13, 11, False), (2, 64, 256, 20, 20, True), (1, 192, 72, 5, 9, False),
