@@ -44,6 +44,7 @@ struct MbParams {
     int nbufX;                // x tile buffers (2: the next tile is prefetched)
     int act_e, act_d, act_p, post;
     uint32_t* ovf;            // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
+    uint32_t* dbg;            // diagnostic builds only (-DMBR_CYCLES): in-kernel stamps
 };
 
 __device__ __forceinline__ int mb_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // [0,2,3,1]

@@ -1,0 +1,472 @@
+// mbr.hpp - the fused inverted-residual unit (1x1 expand + BN + act -> depthwise 3x3 + BN + act -> 1x1 project + BN (+ skip);
+// reference LinearBottleneck.forward, mobilenetv2.py:62-71, dwconv_block, common/conv.py:437-473) with the expanded tensor
+// held in REGISTERS: no LDS traffic inside a tile.
+//
+// mbw.hpp's wave keeps its E (expanded) and D (depthwise output) tiles in LDS: per 32-channel chunk a wave writes 7 KB and reads
+// 54 KB, S2 waits for S1's writes, S3 for S2's, and the 8 waves of a CU need ~250 B/clk of LDS at the rate the matrix pipe could
+// run - round 4 measured the class at 0.13 of HBM with the matrix pipe 27 % busy and no unit saturated. Here:
+//
+//   tile   RO output rows x 14 output columns of one image per wave; its input window is (RO + 2) rows x 16 columns = ONE MFMA
+//          pixel block per window row (lane l: window column l % 16, K quarter l / 16). Every stride-1 map of MobileNetV2 is a
+//          multiple of 14 wide (112, 56, 28, 14).
+//   x      global -> registers as B fragments (16 B = 8 channels of the lane's pixel), one per window row, live for all chunks; the
+//          next tile's rows are requested in the last chunk, each behind the S1 that used the register last.
+//   S1     E row = act(BN(W_exp[chunk] . x row)): two MFMAs; the packed result of lane (pixel, q) is channels 8 q .. 8 q + 7 of that
+//          pixel (the packed weight rows are in MFMA order, igemm_conv.hpp). Pixels outside the image come out 0 (the clamp's
+//          upper bound is the mask, as in mbw.hpp).
+//   taps   the left / right neighbours of a pixel are the neighbouring LANES of its 16-lane row: two DPP moves per dword
+//          (row_shr:1 / row_shl:1, zero fill = the halo lanes 0 and 15, whose outputs are never stored). The rows above / below
+//          are other registers. So the B operand of the depthwise MFMA is assembled from registers:
+//   S2     depthwise 3x3 as block-diagonal MFMAs over 16 channels (half g of the chunk: channels 8 q + 4 g + e) - on the SPARSE
+//          matrix instruction v_smfmac_f32_16x16x64 (2:4 structured-sparse A at twice the K of the dense form for the same 16
+//          cycles; operand layout probed by tests/tools/micro/smfmac_probe.cpp). A diagonal weight matrix has ONE non-zero per
+//          group of four K values (K = tap x 4 channels of a lane), so it is exactly representable. One K = 64 step = 4 tap
+//          slots x 16 channels: R(r) = {left, centre, right, 0} of window row r, and output row u = R(u) W0 + R(u+1) W1 + R(u+2) W2:
+//          3 instructions (the dense form needs 5 for its 10 tap slots), R(r) shared by three output rows. The compressed
+//          fragments are prebuilt once per block in LDS (6 KB per chunk) and read once per chunk.
+//   S3     the packed S2 results of both halves ARE the B fragment of the project GEMM in natural K order (slot s of lane q =
+//          channel 8 q + s): no LDS round trip. acc[Cout][RO x 16] += W_proj[:, chunk] . D
+//   then BN (+ residual) and 16-byte NHWC stores of lanes 1 .. 14.
+// Same rounding points as the three launches (E, D, y rounded to the storage type; fp32 accumulation everywhere).
+// LDS holds only what every wave reads: the 1x1 weights (64-byte swizzled rows as in mbw.hpp), the diagonal fragments, BN constants.
+#pragma once
+#include <type_traits>
+#include "pcv_common.hpp"
+#include "igemm_conv.hpp"     // Mma<DT>
+#include "mbconv.hpp"         // MbParams
+#include "mbw.hpp"            // mbw_swz, mbw_act
+
+struct MbrLds {
+    int wexp, wproj, af, wdw, bn, bnp, total;
+};
+static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks) {
+    MbrLds L;
+    int o = 0;
+    L.wexp = o; o += nChunks * 32 * 64;                 // [chunk][32 rows][64 B]
+    L.wproj = o; o += nChunks * nrt * 16 * 64;          // [chunk][nrt * 16 rows][64 B]
+    L.af = o; o += nChunks * 6 * 1024;                  // [chunk][half g][filter row][lane] 16 B: compressed diagonal depthwise fragments
+    L.wdw = o; o += nChunks * 16 * 64;                  // [chunk][tap (9 of 16)][32 ch] 16-bit: staging for the fragment build
+    L.bn = o; o += nChunks * 4 * 32 * 4;                // [chunk][scale_e, shift_e, scale_d, shift_d][32 ch] fp32
+    L.bnp = o; o += 2 * nrt * 16 * 4;                   // scale_p, shift_p
+    L.total = o;
+    return L;
+}
+// timing experiments only (tests/tools/sh/mbr_variants.sh builds one library per value; results are WRONG with any bit set):
+// 1: one S2 MFMA instead of five   2: no DPP moves   4: no epilogue   8: no S3   16: no S1 epilogue (BN / clamp)   32: no x loads in the loop
+#ifndef MBR_DBG
+#define MBR_DBG 0
+#endif
+
+constexpr int kMbrCols = 14;                            // output columns of a wave tile (window = 16 columns = one MFMA pixel block)
+
+// v_smfmac_f32_16x16x64_{f16,bf16}: D(16x16) += A(16x64, 2:4 sparse) . B(64x16). Operand layout as measured on gfx950
+// (tests/tools/micro/smfmac_probe.cpp): K = two halves of 32. B lane (column n = l % 16, kq = l / 16) element e (16 per lane): half
+// e / 8, dense K = 8 kq + e % 8 inside the half - i.e. FOUR groups of four consecutive K per lane. A lane (row i = l % 16, q = l / 16)
+// holds 8 compressed values = 4 slot pairs m: pair m keeps two of the four dense values of B's group (kq, gb) with
+// kq = 2 (q & 1) + m / 2, gb = 2 (q / 2) + m % 2; every 4-bit field p0 | p1 << 2 of the index register names their positions
+// (slot 2 m <- position p0, slot 2 m + 1 <- position p1). 16.2 cycles per instruction, as the dense 16x16x32.
+template <int DT> struct MmaSp;
+template <> struct MmaSp<PCV_F16> {
+    typedef __attribute__((ext_vector_type(16))) _Float16 bfrag;
+    static __device__ __forceinline__ f32x4 run(const f16x8& a, const bfrag& b, f32x4 c, int idx) {
+        return __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, c, idx, 0, 0);
+    }
+};
+template <> struct MmaSp<PCV_BF16> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 afrag;
+    typedef __attribute__((ext_vector_type(16))) __bf16 bfrag;
+    static __device__ __forceinline__ f32x4 run(const s16x8& a, const bfrag& b, f32x4 c, int idx) {
+        return __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(afrag, a), b, c, idx, 0, 0);
+    }
+};
+typedef __attribute__((ext_vector_type(8))) uint32_t u32x8;
+
+// fp16 pair {clamp(a0 s0 + h0, 0, 1), clamp(a1 s1 + h1, 0, 1)}: hipcc selects v_fma_mixlo_f16 / v_fma_mixhi_f16 with the clamp
+// modifier for exactly this shape (fp32 FMA, rounded once, the PACKED pair clamped: 0 and 1 are fp16 values, so clamping before or
+// after the rounding is the same)
+__device__ __forceinline__ uint32_t mbr_bn_clamp01(float a0, float s0, float h0, float a1, float s1, float h1) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    h2 r = {(_Float16)__builtin_fmaf(a0, s0, h0), (_Float16)__builtin_fmaf(a1, s1, h1)};
+    const h2 zero = {(_Float16)0.f, (_Float16)0.f}, one = {(_Float16)1.f, (_Float16)1.f};
+    r = __builtin_elementwise_min(__builtin_elementwise_max(r, zero), one);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+template <int CTRL> __device__ __forceinline__ uint32_t mbr_dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);      // bound_ctrl: lanes shifted in read 0
+}
+
+// NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise stages when both
+// are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; RO: output rows of a wave tile. Stride 1, Cin <= 32. blockDim.x = 512.
+template <int DT, int NRT, int ACT, int RO>
+__global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NR = RO + 2;                          // window rows
+    // fp16 + ReLU6 (MobileNetV2's default mode): E and D are kept as E / 6 and D / 6 in [0, 1], so that BN + rounding + clamp of a pair
+    // is TWO instructions, v_fma_mixlo_f16 / v_fma_mixhi_f16 with the clamp modifier (the generic path: two FMAs, a conversion, two
+    // packed clamps - and a dependent chain of four where the loop is bound by exactly such chains: removing the 72 DPP moves of a
+    // chunk changed nothing, removing the S1 epilogue took 18 % off). The factors are folded into the fp32 BN constants when they are
+    // copied to LDS: scale_e / 6, shift_e / 6, shift_d / 6, 6 scale_p. Rounding E / 6 instead of E is a different but equally good
+    // 11-bit rounding of the same fp32 value (the tests bound the difference to the three separate launches at 2 ulp of the output).
+    constexpr bool FAST = DT == PCV_F16 && ACT == PCV_ACT_RELU6;
+    if constexpr (FAST) __builtin_amdgcn_s_setreg(1 | (8 << 6), 0);      // MODE.DX10_CLAMP = 0: the clamp modifier passes NaN through (as torch's hardtanh)
+    typedef typename Mma<DT>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const MbrLds L = mbr_lds_layout(NRT, p.nChunks);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nWaves = blockDim.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    char* const Wes = smem + L.wexp;
+    char* const Wps = smem + L.wproj;
+    char* const Afs = smem + L.af;
+    float* const BNs = reinterpret_cast<float*>(smem + L.bn);
+#ifdef MBR_CYCLES      // diagnostic build (tests/tools/mbr_cycles.py): shader-cycle stamps of the prologue and of this wave's second tile
+    const uint64_t k0__ = __builtin_amdgcn_s_memtime();
+    uint64_t k1__ = 0;
+    int ntile__ = 0;
+#endif
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res ? p.y_bytes : 0, 0x00020000);
+
+    // ---- the unit's weights and BN constants -> LDS, once per block -------------------------------------------------------------------
+    // ONE loop over every 16-byte piece of the five tables, four independent loads in flight per thread: as five loops of
+    // load -> store the prologue measured 10 K cycles (every iteration a full L2 latency, the fragment build two dependent 2-byte
+    // loads per entry), 4 - 14 % of a launch. Pieces beyond a table's end (padded rows / channels) are stored as zeros.
+    {
+        const int nA = p.nChunks * 128, nB = p.nChunks * NRT * 64, nC = p.nChunks * 64, nD = p.nChunks * 32, nE = 8 * NRT;
+        const int total = nA + nB + nC + nD + nE;
+        char* const Wds = smem + L.wdw;
+        for (int base = tid; base < total; base += 4 * blockDim.x) {
+            u32x4 v[4];
+            float fold[4];
+            char* dst[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int i = base + k * blockDim.x;
+                const char* src = nullptr;
+                bool ok = false;
+                dst[k] = nullptr;
+                if (i < nA) {                                                      // expand weights: row = 32 c + r in MFMA order
+                    const int slot = i & 3, row = i >> 2;
+                    const uint32_t off = (uint32_t)((row * p.Kpad1 + 8 * slot) * 2);
+                    src = static_cast<const char*>(p.w_exp) + off; ok = off + 16u <= p.wexp_bytes;
+                    dst[k] = Wes + row * 64 + ((slot ^ mbw_swz<true>(row)) << 4);
+                } else if ((i -= nA) < nB) {                                       // projection weights: K slice 32 c of every row
+                    const int slot = i & 3, row = (i >> 2) % (NRT * 16), c = (i >> 2) / (NRT * 16);
+                    const uint32_t off = (uint32_t)((row * p.Kpad2 + 32 * c + 8 * slot) * 2);
+                    src = static_cast<const char*>(p.w_proj) + off; ok = off + 16u <= p.wproj_bytes;
+                    dst[k] = Wps + (c * NRT * 16 + row) * 64 + ((slot ^ mbw_swz<true>(row)) << 4);
+                } else if ((i -= nB) < nC) {                                       // depthwise taps [9][Cmid] -> [chunk][tap][32]
+                    const int pc = i & 3, t = (i >> 2) & 15, ch = 32 * (i >> 6) + 8 * pc;
+                    src = static_cast<const char*>(p.w_dw) + (t * p.Cmid + ch) * 2; ok = t < 9 && ch < p.Cmid;
+                    dst[k] = Wds + i * 16;
+                } else if ((i -= nC) < nD) {                                       // BN of the expand / depthwise stages -> [chunk][which][32]
+                    const int pc = i & 7, which = (i >> 3) & 3, ch = 32 * (i >> 5) + 4 * pc;
+                    const float* arr = which == 0 ? p.scale_e : which == 1 ? p.shift_e : which == 2 ? p.scale_d : p.shift_d;
+                    src = reinterpret_cast<const char*>(arr + ch); ok = arr != nullptr && ch < p.Cmid;
+                    dst[k] = reinterpret_cast<char*>(BNs) + i * 16;
+                } else if ((i -= nD) < nE) {                                       // BN of the projection
+                    const int which = i / (NRT * 4), ch = (i % (NRT * 4)) * 4;
+                    src = reinterpret_cast<const char*>((which ? p.shift_p : p.scale_p) + ch); ok = ch < p.Cout;
+                    dst[k] = smem + L.bnp + i * 16;
+                }
+                v[k] = ok ? *reinterpret_cast<const u32x4*>(src) : (u32x4){0u, 0u, 0u, 0u};
+                fold[k] = 1.f;
+                if constexpr (FAST) {
+                    const int j = base + k * (int)blockDim.x - nA - nB - nC;      // position inside the BN tables
+                    if (j >= 0 && j < nD) fold[k] = ((j >> 3) & 3) == 2 ? 1.f : (1.f / 6.f);
+                    else if (j >= nD && j < nD + nE) fold[k] = (j - nD) < NRT * 4 ? 6.f : 1.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (FAST) {
+                    if (fold[k] != 1.f) v[k] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, v[k]) * fold[k]);
+                }
+                if (dst[k] != nullptr) *reinterpret_cast<u32x4*>(dst[k]) = v[k];
+            }
+        }
+        __syncthreads();
+        // compressed diagonal depthwise fragments (MmaSp): A lane (row i, quarter q) of (chunk c, half g, filter row dy). Row i is channel
+        // 32 c + 8 (i / 4) + 4 g + i % 4, which B's lane quarter i / 4 supplies at position i % 4 of its groups gb = 0 1 2 (left, centre,
+        // right tap; group 3 is padding): slot pair m of this lane is non-zero when it faces that quarter and a tap group.
+        const uint16_t* const wd = reinterpret_cast<const uint16_t*>(Wds);
+#pragma unroll 4
+        for (int idx = tid; idx < p.nChunks * 6 * 64; idx += blockDim.x) {
+            const int l = idx & 63, dy = (idx >> 6) % 3, g = ((idx >> 6) / 3) & 1, c = (idx >> 6) / 6;
+            const int i = l & 15, q = l >> 4;
+            const int chl = 8 * (i >> 2) + 4 * g + (i & 3);                          // channel inside the chunk
+            u32x4 a4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int kq = 2 * (q & 1) + (m >> 1), gb = 2 * (q >> 1) + (m & 1);
+                const uint32_t w = (kq == (i >> 2) && gb < 3) ? wd[(c * 16 + 3 * dy + gb) * 32 + chl] : 0u;
+                a4[m] = (i & 3) == 3 ? w << 16 : w;                                 // positions (i % 4, 3), or (0, 3) for i % 4 == 3: see spidx
+            }
+            *reinterpret_cast<u32x4*>(Afs + (size_t)idx * 16) = a4;
+        }
+    }
+    __syncthreads();
+
+#ifdef MBR_CYCLES
+    k1__ = __builtin_amdgcn_s_memtime();
+#endif
+    const ActClamp act_e = make_act(p.act_e), act_d = make_act(p.act_d), act_p = make_act(p.act_p), post = make_act(p.post);
+
+    const int fsw = (fq ^ mbw_swz<true>(fr)) << 4;                                   // fragment access of row (16 k + fr), slot fq
+    const char* const we_rd = Wes + fr * 64 + fsw;
+    const char* const wp_rd = Wps + fr * 64 + fsw;
+    const char* const af_rd = Afs + lane * 16;
+    // sparse index of this lane's A rows (MmaSp): every group keeps positions (i % 4, 3) - the weight in the pair's first slot, a zero in
+    // the second - or (0, 3) with the weight second for i % 4 == 3; all eight 4-bit fields alike
+    const int spidx = (((fr & 3) == 3 ? 0 : (fr & 3)) | (3 << 2)) * 0x11111111;
+
+    const int nWavesAll = gridDim.x * nWaves;
+    int tile = blockIdx.x * nWaves + wave;
+    const bool resx = NRT == 2 && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
+
+    // A tile's position, decoded ONCE (three scalar divisions; decoded inside every row load the epilogue's prefetch alone was ~700
+    // scalar instructions per tile): image, first output row, this lane's window column and the byte offset of its pixel in window row 0
+    struct TilePos { int n, h0, wi; bool colok; int off0; };
+    auto decode = [&](int t) __attribute__((always_inline)) -> TilePos {
+        TilePos T;
+        const int tw = t % p.tilesW;
+        const int t2 = t / p.tilesW;
+        const int th = t2 % p.tilesH;
+        T.n = t2 / p.tilesH;
+        T.h0 = th * RO;
+        T.wi = tw * kMbrCols - 1 + fr;
+        T.colok = (t < p.nTiles) & ((unsigned)T.wi < (unsigned)p.W) & (8 * fq < p.Cin);
+        T.off0 = (((T.n * p.H + T.h0 - 1) * p.W + T.wi) * p.Cin + 8 * fq) * 2;                          // < 2 GiB: checked by the host
+        return T;
+    };
+    const int rowpitch = p.W * p.Cin * 2;
+    // x fragment of window row r (window rows h0 - 1 .. h0 + RO, columns w0 - 1 .. w0 + 14)
+    auto load_x = [&](const TilePos& T, int r) __attribute__((always_inline)) -> u32x4 {
+        const bool ok = T.colok & ((unsigned)(T.h0 - 1 + r) < (unsigned)p.H);
+        return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 + r * rowpitch) : 0x80000000u, 0, 0);
+    };
+
+    TilePos cur = decode(tile);
+    u32x4 xr[NR];
+    if (tile < p.nTiles) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) xr[r] = load_x(cur, r);
+    }
+
+    while (tile < p.nTiles) {
+        const int ntile = tile + nWavesAll;
+        const TilePos nxt = decode(ntile);
+        const int n = cur.n, h0 = cur.h0, wi = cur.wi;
+        const bool colok = (unsigned)wi < (unsigned)p.W;
+
+#ifdef MBR_CYCLES
+        const bool stamp__ = p.dbg != nullptr && ntile__ == 1;
+        ++ntile__;
+        uint64_t c0__ = 0, c1__ = 0;
+        if (stamp__) c0__ = __builtin_amdgcn_s_memtime();
+#endif
+        f32x4 acc[NRT][RO];
+#pragma unroll
+        for (int i = 0; i < NRT; ++i)
+#pragma unroll
+            for (int u = 0; u < RO; ++u) acc[i][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int c = 0; c < p.nChunks; ++c) {
+            const bool last = c + 1 == p.nChunks;
+            F16Guard<DT, true> g1, g2;                                // fp16 range checks of this chunk's E / D values (unbounded activations only)
+            u32x2 d0[RO];                                             // half 0 of the D rows, kept until half 1 completes the K step of S3
+            // The two 16-channel halves of the chunk are two passes over the tile: S1's two MFMAs are independent (fragment g of the
+            // expand weights gives exactly the channels 8 q + 4 g + e that S2's half g convolves), so a pass holds 3 diagonal
+            // fragments, one expand fragment and one half's BN constants (both halves at once spilled: 256 registers).
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                frag af[3];
+                const frag we = *reinterpret_cast<const frag*>(we_rd + (32 * c + 16 * g) * 64);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) af[j] = *reinterpret_cast<const frag*>(af_rd + ((c * 2 + g) * 3 + j) * 1024);
+                // BN constants of this lane's 4 channels 32 c + 8 fq + 4 g + e: the same channels in S1 (accumulator rows) and S2
+                f32x4 se = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 8 * fq + 4 * g);
+                f32x4 he = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 32 + 8 * fq + 4 * g);
+                if constexpr (FAST) {                                  // columns outside the image: E = clamp(0 . acc + 0) = 0
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        se[e] = colok ? se[e] : 0.f;
+                        he[e] = colok ? he[e] : 0.f;
+                    }
+                }
+                const f32x4 sd = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 64 + 8 * fq + 4 * g);
+                const f32x4 hd = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 96 + 8 * fq + 4 * g);
+                frag wp[NRT];
+                if (g == 1) {
+#pragma unroll
+                    for (int i = 0; i < NRT; ++i) wp[i] = *reinterpret_cast<const frag*>(wp_rd + ((c * NRT + i) * 16) * 64);
+                }
+
+                // Window row r is used the moment it exists: its tuple R(r) = {left, centre, right, 0} is filter row 2 of output row r - 2,
+                // filter row 1 of output row r - 1 and filter row 0 of output row r - three sparse MFMAs on three DIFFERENT accumulators
+                // (as a chain of three on one accumulator, written when the last of three window rows arrived, every removed MFMA
+                // saved twice its pipe time: the chain was the critical path; in-kernel stamps).
+                f32x4 da[RO + 2];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    // ---- S1: window row r of the E half-chunk ----------------------------------------------------------------------
+                    u32x8 b8;
+                    {
+                        const f32x4 e0 = Mma<DT>::run(we, __builtin_bit_cast(frag, xr[r]), (f32x4){0.f, 0.f, 0.f, 0.f});
+                        // the next tile's row into the register this S1 used last (rows that are the unit's skip tensor: behind the epilogue)
+                        if ((MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) xr[r] = load_x(nxt, r);
+                        uint32_t o[2];
+                        if constexpr (FAST) {
+                            const uint32_t rowmask = (unsigned)(h0 - 1 + r) < (unsigned)p.H ? 0xFFFFFFFFu : 0u;      // (scalar) rows outside the image
+                            o[0] = mbr_bn_clamp01(e0[0], se[0], he[0], e0[1], se[1], he[1]) & rowmask;
+                            o[1] = mbr_bn_clamp01(e0[2], se[2], he[2], e0[3], se[3], he[3]) & rowmask;
+                        } else {
+                            // (four v_fma_f32, not two v_pk_fma_f32: beside MFMAs a packed fp32 instruction costs several plain ones -
+                            // MI355X_MICROARCH.md, "price of one filler"; mbr_*.hip are built with -fno-slp-vectorize for the same reason)
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(e0[e], se[e], he[e]);
+                            const bool ok = colok & ((unsigned)(h0 - 1 + r) < (unsigned)p.H);   // E is zero outside the image (the depthwise pads the EXPANDED map)
+                            if constexpr (ACT == PCV_ACT_RELU || ACT == PCV_ACT_RELU6) {
+                                const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), hi);
+                                if constexpr (ACT != PCV_ACT_RELU6) g1.see(v);
+                                o[0] = pack2<DT>(v[0], v[1]);
+                                o[1] = pack2<DT>(v[2], v[3]);
+                            } else {
+                                apply_actn<4>(v, act_e);
+                                g1.see(v);
+                                o[0] = ok ? pack2<DT>(v[0], v[1]) : 0u;
+                                o[1] = ok ? pack2<DT>(v[2], v[3]) : 0u;
+                            }
+                        }
+                        if constexpr ((MBR_DBG & 16) != 0) {
+                            o[0] = __float_as_uint(e0[0]) ^ __float_as_uint(e0[1]);
+                            o[1] = __float_as_uint(e0[2]) ^ __float_as_uint(e0[3]);
+                        }
+                        if constexpr ((MBR_DBG & 2) != 0) b8 = (u32x8){o[0], o[1], o[0], o[1], o[0], o[1], 0u, 0u};
+                        else b8 = (u32x8){mbr_dpp<0x111>(o[0]), mbr_dpp<0x111>(o[1]), o[0], o[1], mbr_dpp<0x101>(o[0]), mbr_dpp<0x101>(o[1]), 0u, 0u};   // row_shr:1 = the pixel to the left, row_shl:1 = to the right
+                    }
+                    // ---- S2: filter row 2 of output row r - 2 (complete behind it), 1 of r - 1, 0 of r ------------------------------------
+                    const typename MmaSp<DT>::bfrag R = __builtin_bit_cast(typename MmaSp<DT>::bfrag, b8);
+                    if (r >= 2) da[r - 2] = MmaSp<DT>::run(af[2], R, da[r - 2], spidx);
+                    if ((MBR_DBG & 1) == 0 && r >= 1 && r - 1 < RO) da[r - 1] = MmaSp<DT>::run(af[1], R, da[r - 1], spidx);
+                    if (r < RO) {
+                        if constexpr ((MBR_DBG & 1) == 0) da[r] = MmaSp<DT>::run(af[0], R, (f32x4){0.f, 0.f, 0.f, 0.f}, spidx);
+                        else da[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    // ---- BN + act of the finished row (+ S3 behind the second half) -----------------------------------------------------
+                    if (r >= 2) {
+                        const int u = r - 2;
+                        u32x2 od;
+                        if constexpr (FAST) {
+                            od[0] = mbr_bn_clamp01(da[u][0], sd[0], hd[0], da[u][1], sd[1], hd[1]);
+                            od[1] = mbr_bn_clamp01(da[u][2], sd[2], hd[2], da[u][3], sd[3], hd[3]);
+                        } else {
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(da[u][e], sd[e], hd[e]);
+                            mbw_act<ACT, 4>(v, act_d);
+                            if constexpr (ACT != PCV_ACT_RELU6) g2.see(v);
+                            od[0] = pack2<DT>(v[0], v[1]);
+                            od[1] = pack2<DT>(v[2], v[3]);
+                        }
+                        if (g == 0) {
+                            d0[u] = od;
+                        } else {
+                            const frag b = __builtin_bit_cast(frag, (u32x4){d0[u][0], d0[u][1], od[0], od[1]});
+#pragma unroll
+                            for (int i = 0; i < ((MBR_DBG & 8) ? 1 : NRT); ++i) acc[i][u] = Mma<DT>::run(wp[i], b, acc[i][u]);
+                        }
+                    }
+                }
+            }
+            if constexpr (ACT != PCV_ACT_RELU6) {
+                g1.commit(p.ovf);
+                g2.commit(p.ovf);
+            }
+        }
+
+#ifdef MBR_CYCLES
+        if (stamp__) c1__ = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- epilogue: BN (+ residual), 16-byte NHWC stores of the 14 inner lanes ------------------------------------------------------
+        // The skip tensor of a LinearBottleneck is the unit's input: window row u + 1 of x, which this lane still holds as a B
+        // fragment (same pixel, same 8 channels). Loaded from memory row by row, behind a uniform branch each, the seven dependent
+        // round trips were 28 % of a tile (in-kernel stamps); a skip tensor that is NOT x is requested for all rows up front.
+        F16Guard<DT, true> guard;
+        // plain: no activation behind the projection or behind the skip add (every LinearBottleneck): no uniform branches per row
+        auto epilogue = [&](auto plain) __attribute__((always_inline)) {
+        const bool lane_out = (fr >= 1) & (fr <= kMbrCols) & colok;
+        const float* const BNp = reinterpret_cast<const float*>(smem + L.bnp);
+#pragma unroll
+        for (int ipp = 0; ipp < ((MBR_DBG & 4) ? 0 : NRT / 2); ++ipp) {
+            const int ch = 32 * ipp + 8 * fq;
+            f32x4 sp[2], hp[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sp[h] = *reinterpret_cast<const f32x4*>(BNp + ch + 4 * h);
+                hp[h] = *reinterpret_cast<const f32x4*>(BNp + NRT * 16 + ch + 4 * h);
+            }
+#pragma unroll
+            for (int u = 0; u < RO; ++u) {
+                const int ho = h0 + u;
+                const bool ok = lane_out & (ch < p.Cout) & (ho < p.Ho);
+                const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wi) * p.Cout + ch) * 2) : 0x80000000u;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[2 * ipp][u][e] * sp[0][e] + hp[0][e];
+                    v[4 + e] = acc[2 * ipp + 1][u][e] * sp[1][e] + hp[1][e];
+                }
+                if constexpr (!decltype(plain)::value) apply_act8(v, act_p);
+                if (p.res != nullptr && ipp == 0) {                      // (a skip tensor implies Cout == Cin <= 32: one channel pair of tiles)
+                    const u32x4 r4 = resx ? xr[u + 1] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float r0, r1;
+                        unpack2<DT>(r4[e], r0, r1);
+                        v[2 * e] += r0;
+                        v[2 * e + 1] += r1;
+                    }
+                    if constexpr (!decltype(plain)::value) apply_act8(v, post);
+                }
+                if ((MBR_DBG & 32) == 0 && ipp == 0 && resx) xr[u + 1] = load_x(nxt, u + 1);
+                if (ok) guard.see(v);                                  // (halo lanes hold garbage that is never stored)
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off, 0, 0);
+            }
+        }
+        };
+        if (p.act_p == PCV_ACT_NONE && p.post == PCV_ACT_NONE) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        guard.commit(p.ovf);
+        if constexpr ((MBR_DBG & 4) != 0) {                             // keep the accumulators alive
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < NRT; ++i)
+#pragma unroll
+                for (int u = 0; u < RO; ++u) t += acc[i][u][0] + acc[i][u][1] + acc[i][u][2] + acc[i][u][3];
+            if (t == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), yrsrc, 0, 0, 0);
+        }
+#ifdef MBR_CYCLES
+        if (stamp__ && lane == 0) {
+            const uint64_t c2 = __builtin_amdgcn_s_memtime();
+            uint32_t* d = p.dbg + (blockIdx.x * 8 + wave) * 4;
+            d[0] = (uint32_t)(k1__ - k0__); d[1] = (uint32_t)(c1__ - c0__); d[2] = (uint32_t)(c2 - c1__); d[3] = 1u;
+        }
+#endif
+        tile = ntile;
+        cur = nxt;
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}

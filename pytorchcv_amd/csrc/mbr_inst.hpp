@@ -1,0 +1,9 @@
+// mbr_inst.hpp - the instantiations of mbr_kernel (mbr_bf16.hip / mbr_f16.hip define them, pcv_api.hip sees `extern template`).
+//   X(DT, NRT, ACT, RO): 16-row tiles of the projection, compile-time inner activation (-1: launch-time), output rows of a wave tile
+#pragma once
+#include "mbr.hpp"
+
+#define MBR_SHAPES2(X, DT, NRT, RO) X(DT, NRT, -1, RO) X(DT, NRT, PCV_ACT_RELU, RO) X(DT, NRT, PCV_ACT_RELU6, RO)
+#define MBR_SHAPES(X, DT) MBR_SHAPES2(X, DT, 2, 7) MBR_SHAPES2(X, DT, 4, 4)
+#define MBR_DEFINE(DT, NRT, ACT, RO) template __global__ void mbr_kernel<DT, NRT, ACT, RO>(const MbParams);
+#define MBR_DECLARE(DT, NRT, ACT, RO) extern template __global__ void mbr_kernel<DT, NRT, ACT, RO>(const MbParams);

@@ -22,12 +22,15 @@
 #include "gconv3x3r.hpp"
 #include "mbconv.hpp"
 #include "mbw_inst.hpp"
+#include "mbr_inst.hpp"
 MBW_SHAPES(MBW_DECLARE, PCV_BF16)
 MBW_SHAPES(MBW_DECLARE, PCV_F16)
 MBW2_SHAPES(MBW2_DECLARE, PCV_BF16)
 MBW2_SHAPES(MBW2_DECLARE, PCV_F16)
 MBW3_SHAPES(MBW3_DECLARE, PCV_BF16)
 MBW3_SHAPES(MBW3_DECLARE, PCV_F16)
+MBR_SHAPES(MBR_DECLARE, PCV_BF16)
+MBR_SHAPES(MBR_DECLARE, PCV_F16)
 #include "dwconv.hpp"
 #include "aux_kernels.hpp"
 #include "head_gemm.hpp"
@@ -62,6 +65,7 @@ struct pcv_ctx {
     int persist_mode = 1;       // 1 always (measured best on every ResNet-50 layer), 0 never, -1 by K-steps (PCV_AMD_PERSIST)
     int force_tile = -1;        // tuning only: force the implicit-GEMM tile (0..3) where legal
     int use_wstat = 1;          // weight-stationary persistent mode for single-K-step layers
+    int use_mbr = 1;            // stride-1 fused inverted-residual units with Cin <= 32 run the register-resident kernel (mbr.hpp); 0: mbw.hpp / mbconv.hpp
     int use_mbw = 1;            // fused inverted-residual units with Cin <= 32 run the wave-private kernel (mbw.hpp; 8 / 16: force that pixel-block width); 0: mbconv.hpp
     int use_gconvr = 1;         // grouped 3x3 stride 2 / 32 channels per group on the row-tile kernel (gconv3x3r.hpp); 0 = generic implicit GEMM
     int use_d1x1 = -1;          // K-heavy 1x1 layers on d3q_kernel's 1x1 mode: -1 = pick_d1x1, 0 = never, n > 0 = force shape n - 1 where eligible
@@ -663,6 +667,16 @@ static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka, 
         if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw && e.ka == ka && e.rb == rb) return e.fn;
     return nullptr;
 }
+// register-resident variant (mbr.hpp): stride 1, Cin <= 32, Cout <= 64
+struct MbrEntry { int dt, nrt, act, ro; mbconv_fn fn; };
+#define MBR_ROW(DT, NRT, ACT, RO) {DT, NRT, ACT, RO, mbr_kernel<DT, NRT, ACT, RO>},
+static const MbrEntry kMbr[] = {MBR_SHAPES(MBR_ROW, PCV_BF16) MBR_SHAPES(MBR_ROW, PCV_F16)};
+static const MbrEntry* pick_mbr(int dt, int nrt, int act) {
+    if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
+    for (const MbrEntry& e : kMbr)
+        if (e.dt == dt && e.nrt == nrt && e.act == act) return &e;
+    return nullptr;
+}
 static const int kMbwMaxLds = 160 * 1024;
 // waves per block (one block per CU): as many of 8 / 6 / 4 as the LDS holds beside the unit's weights; 0 = does not fit
 static int mbw_waves(int stride, int nrt, int nChunks, int tw, int ka, int rb) {
@@ -688,6 +702,8 @@ static int enable_mbconv(pcv_ctx* ctx) {
                     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pick_mbconv(dt, s, e != 0, rt)),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kMbMaxLds));
     for (const MbwEntry& e : kMbw)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
+    for (const MbrEntry& e : kMbr)
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(e.fn), hipFuncAttributeMaxDynamicSharedMemorySize, kMbwMaxLds));
     return PCV_OK;
 }
@@ -853,6 +869,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d1x1") ctx->use_d1x1 = value;
     else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
+    else if (k == "mbr") ctx->use_mbr = value;
     else if (k == "dbg") {
 #ifdef PCV_DBG_FLAGS
         ctx->dbg_flags = value;
@@ -2095,6 +2112,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     std::memset(&p, 0, sizeof(p));
     const int S = d_dw->stride_h;
     p.x = x; p.res = d_proj->has_residual ? residual : nullptr; p.y = y; p.ovf = ctx->ovf;
+    p.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
     p.w_exp = d_exp ? static_cast<const char*>(packed_exp) + Pe.ktab_bytes : nullptr;
     p.w_dw = packed_dw;
     p.w_proj = static_cast<const char*>(packed_proj) + Pp.ktab_bytes;
@@ -2120,6 +2138,20 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     int kaw = 0, nrt = 0, rbw = 0;
     const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt, &rbw);
     const bool block_shape = p.Cout <= 32 && p.Wo >= 24;
+    // register-resident tiles (mbr.hpp): stride 1, one expand K step, the unit's weights + diagonal fragments in LDS
+    if (wave_shape && ctx->use_mbr && S == 1 && kaw == 1 && nrt <= 4 && mbr_lds_layout(nrt, p.nChunks).total <= kMbwMaxLds) {
+        const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1);
+        if (e) {
+            p.tilesH = (p.Ho + e->ro - 1) / e->ro; p.tilesW = (p.Wo + kMbrCols - 1) / kMbrCols;
+            const long nT = (long)p.N * p.tilesH * p.tilesW;
+            if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
+            p.nTiles = (int)nT;
+            const unsigned gridr = (unsigned)std::min<long>((nT + 7) / 8, (long)block_slots(ctx, 1));
+            hipLaunchKernelGGL(e->fn, dim3(gridr), dim3(512), mbr_lds_layout(nrt, p.nChunks).total, (hipStream_t)stream, p);
+            HIP_TRY(ctx, hipGetLastError());
+            return PCV_OK;
+        }
+    }
     if (wave_shape && (ctx->use_mbw || !block_shape)) {
         // pixel-block shape: 1 x 16 or 2 x 8 outputs, whichever covers the map with less expand work (window blocks x tiles)
         const int nblk = rbw > 0 ? rbw : (S == 1 ? 4 : 2);

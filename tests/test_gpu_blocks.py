@@ -325,13 +325,14 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["wave", "wave8", "wave16", "block"])
+@pytest.mark.parametrize("kernel", ["reg", "wave", "wave8", "wave16", "block"])
 @pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
 def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype, grid, cuda_device):
     """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
     launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle.
-    `kernel`: wave-private tiles (csrc/mbw.hpp, units with at most 32 input channels; pixel blocks of 2 x 8 or 1 x 16 outputs,
-    chosen by the library or forced) or block tiles (csrc/mbconv.hpp)."""
+    `kernel`: register-resident tiles (csrc/mbr.hpp: stride 1, at most 32 input channels - what the library picks where it
+    applies; other shapes fall through to the wave-private kernel), wave-private tiles (csrc/mbw.hpp, units with at most 32 input
+    channels; pixel blocks of 2 x 8 or 1 x 16 outputs, chosen by the library or forced) or block tiles (csrc/mbconv.hpp)."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.mobilenetv2 import LinearBottleneck
@@ -350,7 +351,7 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype,
     a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
     residual = a if unit.residual else None
     with torch.no_grad():
-        with util.tuning(max_blocks=grid, mbw={"wave": 1, "wave8": 8, "wave16": 16, "block": 0}[kernel]):
+        with util.tuning(max_blocks=grid, mbr=int(kernel == "reg"), mbw={"reg": 1, "wave": 1, "wave8": 8, "wave16": 16, "block": 0}[kernel]):
             fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
         if act is None:
             assert fused is None, "576 expanded channels x 96 inputs do not fit the LDS budget: must fall back"
