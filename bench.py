@@ -76,7 +76,7 @@ def kernel_class_of(name: str):
         return "grouped3x3"
     if ("dwconv_kernel" in name or "dwconv5_kernel" in name) and "pack_" not in name:
         return "depthwise"
-    if "mbw_kernel" in name or "mbconv_kernel" in name:
+    if "mbr_kernel" in name or "mbw_kernel" in name or "mbconv_kernel" in name:
         return "fused_unit"
     if "stem_conv_kernel" in name:
         return "stem"

@@ -44,6 +44,15 @@ struct D3KCfg {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// Wait states between an inline-asm MFMA and the first vector instruction that touches its accumulator, inserted by hand because the
+// compiler pads nothing for an asm statement (cdna_hip_programming.md section 5.7). -DD3K_DROP_HAZARD_PADS (tests/test_isa_hazards.py
+// ONLY) removes them, to prove that the checker notices.
+#ifdef D3K_DROP_HAZARD_PADS
+#define D3K_MFMA_PAD ""
+#else
+#define D3K_MFMA_PAD "s_nop 11"
+#endif
+
 // c = a . b (+ c) with the A fragment in AGPRs (AG) or VGPRs. No hazard the compiler would have had to pad: B comes from an LDS read (a
 // register dependency it tracks), an accumulator is read by vector instructions a whole pixel block later.
 template <int DT, bool AG, bool ZERO>
@@ -222,7 +231,12 @@ __device__ __forceinline__ void d3k_body(const D3Params& p, char* smem) {
                 // block j - 1's accumulators directly behind that block's last MFMA, inside the matrix pipe's latency (fp16 build: three
                 // blocks of every tile came out wrong). This volatile statement is ordered against the per-step anchors above, so the reads
                 // stay behind two steps (four MFMAs, 64 cycles) of this block.
-                if constexpr (kh == 2) asm volatile("" : "+v"(cacc[(j - 1) & 1][0]), "+v"(cacc[(j - 1) & 1][1]));
+                // The distance is ENFORCED, not assumed: only each step's [1]-MFMA is ordered against the volatile anchors, the
+                // [0]-MFMAs are free to sink - hipcc 7.2 moved block j - 1's last MFMA to within 2 - 3 instructions of the first read. The
+                // wait states of the matrix pipe (XDL write -> vector read: passes + 3 on gfx950, 11 for an 8-pass instruction) are
+                // therefore part of this statement, which the accumulators' data dependence pins between the block's last MFMA and
+                // the first read; tests/test_isa_hazards.py checks the emitted code. 12 cycles per 72-MFMA block.
+                if constexpr (kh == 2) asm volatile(D3K_MFMA_PAD : "+v"(cacc[(j - 1) & 1][0]), "+v"(cacc[(j - 1) & 1][1]));
                 if constexpr (kh == 2) epi_part(HRc, JP{}, std::integral_constant<int, 0>{}, guard);
                 if constexpr (kh == 10) epi_part(HRc, JP{}, std::integral_constant<int, 1>{}, guard);
                 if constexpr (kh == 18) epi_part(HRc, JP{}, std::integral_constant<int, 2>{}, guard);
@@ -250,7 +264,7 @@ __device__ __forceinline__ void d3k_body(const D3Params& p, char* smem) {
             // accumulator the matrix pipe is still writing are inserted by hand (the interleaved parts read theirs two steps behind the
             // block's last MFMA: far enough). Without them the last pixel block of every tile came out wrong.
             // (tied to the accumulators: a free-standing asm is not ordered against the non-volatile MFMA statements)
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(cacc[(NB - 1) & 1][0]), "+v"(cacc[(NB - 1) & 1][1]));
+            asm volatile(D3K_MFMA_PAD : "+v"(cacc[(NB - 1) & 1][0]), "+v"(cacc[(NB - 1) & 1][1]));
             typedef std::integral_constant<int, NB - 1> JL;
             epi_part(HRc, JL{}, std::integral_constant<int, 0>{}, guard); epi_part(HRc, JL{}, std::integral_constant<int, 1>{}, guard);
             epi_part(HRc, JL{}, std::integral_constant<int, 2>{}, guard); epi_part(HRc, JL{}, std::integral_constant<int, 3>{}, guard);

@@ -33,7 +33,7 @@ struct DwParams {
     int nseg;             // ceil(Ho / TH)
     int act, post_act;
     long total;           // N * nseg * Wo * C8
-    int flags;            // tuning: bit 0 = non-temporal output stores
+    int flags;            // tuning: bit 0 = non-temporal output stores, bit 1 = blocks in dispatch order (no XCD remap)
     uint32_t* ovf;        // the context's fp16 overflow counter (pcv_common.hpp, F16Guard)
 };
 
@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_kernel(const DwParams p) {
     constexpr int ES = Elem<DT>::BYTES;
     constexpr int KEEP = KS > S ? KS - S : 0;       // rows shared by consecutive output rows
     constexpr int NEW = KS - KEEP;                  // rows fetched per output row
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    // Neighbouring blocks read overlapping input columns (+-1 column per output column: up to three blocks per line). Blocks b and
+    // b + 8 share an XCD's L2, not b and b + 1: in dispatch order every shared line was fetched into two or three L2s (PMC: 1.33x the
+    // algorithmic bytes at the fabric, which this HBM-bound kernel cannot afford). xcd_remap gives each XCD a contiguous run of blocks.
+    const long idx = (long)((p.flags & 2) ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x)) * 256 + threadIdx.x;      // (flags bit 1: dispatch order, A/B)
     if (idx >= p.total) return;
     const int c8 = (int)(idx % p.C8);
     long t = idx / p.C8;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void dwconv5_kernel(const DwParams p) {
     constexpr int ES = Elem<DT>::BYTES;
     constexpr int NSLOT = S == 1 ? 5 : 3;          // output rows in flight
     constexpr int PERIOD = S == 1 ? 5 : 6;         // input rows after which the (phase -> slot) pattern repeats
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;      // (see dwconv_kernel)
     if (idx >= p.total) return;
     const int c4 = (int)(idx % p.C8);
     long t0 = idx / p.C8;

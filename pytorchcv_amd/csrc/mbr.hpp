@@ -98,10 +98,15 @@ template <int CTRL> __device__ __forceinline__ uint32_t mbr_dpp(uint32_t v) {
 
 // NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise stages when both
 // are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; RO: output rows of a wave tile. Stride 1, Cin <= 32. blockDim.x = 512.
-template <int DT, int NRT, int ACT, int RO>
+template <int DT, int NRT, int ACT, int RO, int S = 1>
 __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NR = RO + 2;                          // window rows
+    // Stride 2 keeps the window layout (16 consecutive input columns per lane row, so the taps of the output centred on lane l are
+    // still lanes l - 1, l, l + 1): the depthwise stage runs on every lane, the outputs are the 7 odd lanes 1 .. 13 (input columns
+    // w0 + 0, 2 .. 12) and every second window row; window row r is filter row 0 of output r / 2 and 2 of r / 2 - 1 (r even) or 1 of
+    // (r - 1) / 2 (r odd). 2 RO + 1 window rows, no skip tensor.
+    constexpr int NR = S == 1 ? RO + 2 : 2 * RO + 1;    // window rows
+    constexpr int OC = S == 1 ? kMbrCols : kMbrCols / 2; // output columns of a tile
     // fp16 + ReLU6 (MobileNetV2's default mode): E and D are kept as E / 6 and D / 6 in [0, 1], so that BN + rounding + clamp of a pair
     // is TWO instructions, v_fma_mixlo_f16 / v_fma_mixhi_f16 with the clamp modifier (the generic path: two FMAs, a conversion, two
     // packed clamps - and a dependent chain of four where the loop is bound by exactly such chains: removing the 72 DPP moves of a
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
 
     const int nWavesAll = gridDim.x * nWaves;
     int tile = blockIdx.x * nWaves + wave;
-    const bool resx = NRT == 2 && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
+    const bool resx = S == 1 && NRT == 2 && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
 
     // A tile's position, decoded ONCE (three scalar divisions; decoded inside every row load the epilogue's prefetch alone was ~700
     // scalar instructions per tile): image, first output row, this lane's window column and the byte offset of its pixel in window row 0
@@ -238,16 +243,16 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
         const int t2 = t / p.tilesW;
         const int th = t2 % p.tilesH;
         T.n = t2 / p.tilesH;
-        T.h0 = th * RO;
-        T.wi = tw * kMbrCols - 1 + fr;
+        T.h0 = th * RO;                                                             // first OUTPUT row
+        T.wi = tw * OC * S - 1 + fr;                                                // this lane's INPUT column
         T.colok = (t < p.nTiles) & ((unsigned)T.wi < (unsigned)p.W) & (8 * fq < p.Cin);
-        T.off0 = (((T.n * p.H + T.h0 - 1) * p.W + T.wi) * p.Cin + 8 * fq) * 2;                          // < 2 GiB: checked by the host
+        T.off0 = (((T.n * p.H + T.h0 * S - 1) * p.W + T.wi) * p.Cin + 8 * fq) * 2;                          // < 2 GiB: checked by the host
         return T;
     };
     const int rowpitch = p.W * p.Cin * 2;
     // x fragment of window row r (window rows h0 - 1 .. h0 + RO, columns w0 - 1 .. w0 + 14)
     auto load_x = [&](const TilePos& T, int r) __attribute__((always_inline)) -> u32x4 {
-        const bool ok = T.colok & ((unsigned)(T.h0 - 1 + r) < (unsigned)p.H);
+        const bool ok = T.colok & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H);
         return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 + r * rowpitch) : 0x80000000u, 0, 0);
     };
 
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                 // filter row 1 of output row r - 1 and filter row 0 of output row r - three sparse MFMAs on three DIFFERENT accumulators
                 // (as a chain of three on one accumulator, written when the last of three window rows arrived, every removed MFMA
                 // saved twice its pipe time: the chain was the critical path; in-kernel stamps).
-                f32x4 da[RO + 2];
+                f32x4 da[RO + 2];                                             // (RO used)
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     // ---- S1: window row r of the E half-chunk ----------------------------------------------------------------------
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                         if ((MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) xr[r] = load_x(nxt, r);
                         uint32_t o[2];
                         if constexpr (FAST) {
-                            const uint32_t rowmask = (unsigned)(h0 - 1 + r) < (unsigned)p.H ? 0xFFFFFFFFu : 0u;      // (scalar) rows outside the image
+                            const uint32_t rowmask = (unsigned)(h0 * S - 1 + r) < (unsigned)p.H ? 0xFFFFFFFFu : 0u;      // (scalar) rows outside the image
                             o[0] = mbr_bn_clamp01(e0[0], se[0], he[0], e0[1], se[1], he[1]) & rowmask;
                             o[1] = mbr_bn_clamp01(e0[2], se[2], he[2], e0[3], se[3], he[3]) & rowmask;
                         } else {
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(e0[e], se[e], he[e]);
-                            const bool ok = colok & ((unsigned)(h0 - 1 + r) < (unsigned)p.H);   // E is zero outside the image (the depthwise pads the EXPANDED map)
+                            const bool ok = colok & ((unsigned)(h0 * S - 1 + r) < (unsigned)p.H);   // E is zero outside the image (the depthwise pads the EXPANDED map)
                             if constexpr (ACT == PCV_ACT_RELU || ACT == PCV_ACT_RELU6) {
                                 const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
@@ -356,15 +361,24 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                     }
                     // ---- S2: filter row 2 of output row r - 2 (complete behind it), 1 of r - 1, 0 of r ------------------------------------
                     const typename MmaSp<DT>::bfrag R = __builtin_bit_cast(typename MmaSp<DT>::bfrag, b8);
-                    if (r >= 2) da[r - 2] = MmaSp<DT>::run(af[2], R, da[r - 2], spidx);
-                    if ((MBR_DBG & 1) == 0 && r >= 1 && r - 1 < RO) da[r - 1] = MmaSp<DT>::run(af[1], R, da[r - 1], spidx);
-                    if (r < RO) {
-                        if constexpr ((MBR_DBG & 1) == 0) da[r] = MmaSp<DT>::run(af[0], R, (f32x4){0.f, 0.f, 0.f, 0.f}, spidx);
-                        else da[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    // (output row that window row r completes: -1 = none)
+                    const int udone = S == 1 ? r - 2 : ((r & 1) == 0 ? r / 2 - 1 : -1);
+                    if constexpr (S == 1) {
+                        if (r >= 2) da[r - 2] = MmaSp<DT>::run(af[2], R, da[r - 2], spidx);
+                        if ((MBR_DBG & 1) == 0 && r >= 1 && r - 1 < RO) da[r - 1] = MmaSp<DT>::run(af[1], R, da[r - 1], spidx);
+                        if (r < RO) {
+                            if constexpr ((MBR_DBG & 1) == 0) da[r] = MmaSp<DT>::run(af[0], R, (f32x4){0.f, 0.f, 0.f, 0.f}, spidx);
+                            else da[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                    } else if ((r & 1) == 0) {
+                        if (r >= 2) da[r / 2 - 1] = MmaSp<DT>::run(af[2], R, da[r / 2 - 1], spidx);
+                        if (r / 2 < RO) da[r / 2] = MmaSp<DT>::run(af[0], R, (f32x4){0.f, 0.f, 0.f, 0.f}, spidx);
+                    } else {
+                        da[r / 2] = MmaSp<DT>::run(af[1], R, da[r / 2], spidx);
                     }
                     // ---- BN + act of the finished row (+ S3 behind the second half) -----------------------------------------------------
-                    if (r >= 2) {
-                        const int u = r - 2;
+                    if (udone >= 0) {
+                        const int u = udone;
                         u32x2 od;
                         if constexpr (FAST) {
                             od[0] = mbr_bn_clamp01(da[u][0], sd[0], hd[0], da[u][1], sd[1], hd[1]);
@@ -404,7 +418,8 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
         F16Guard<DT, true> guard;
         // plain: no activation behind the projection or behind the skip add (every LinearBottleneck): no uniform branches per row
         auto epilogue = [&](auto plain) __attribute__((always_inline)) {
-        const bool lane_out = (fr >= 1) & (fr <= kMbrCols) & colok;
+        const bool lane_out = (fr >= 1) & (fr <= kMbrCols) & colok & (S == 1 || (fr & 1));
+        const int wo = S == 1 ? wi : (wi >> 1);                                   // (stride 2: input column w0 + 2 j = lane 2 j + 1)
         const float* const BNp = reinterpret_cast<const float*>(smem + L.bnp);
 #pragma unroll
         for (int ipp = 0; ipp < ((MBR_DBG & 4) ? 0 : NRT / 2); ++ipp) {
@@ -418,8 +433,8 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
 #pragma unroll
             for (int u = 0; u < RO; ++u) {
                 const int ho = h0 + u;
-                const bool ok = lane_out & (ch < p.Cout) & (ho < p.Ho);
-                const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wi) * p.Cout + ch) * 2) : 0x80000000u;
+                const bool ok = lane_out & (ch < p.Cout) & (ho < p.Ho) & (wo < p.Wo);
+                const uint32_t off = ok ? (uint32_t)(((((long)n * p.Ho + ho) * p.Wo + wo) * p.Cout + ch) * 2) : 0x80000000u;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                 }
                 if constexpr (!decltype(plain)::value) apply_act8(v, act_p);
                 if (p.res != nullptr && ipp == 0) {                      // (a skip tensor implies Cout == Cin <= 32: one channel pair of tiles)
-                    const u32x4 r4 = resx ? xr[u + 1] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                    const u32x4 r4 = resx ? xr[S == 1 ? u + 1 : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float r0, r1;
@@ -438,7 +453,9 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                     }
                     if constexpr (!decltype(plain)::value) apply_act8(v, post);
                 }
-                if ((MBR_DBG & 32) == 0 && ipp == 0 && resx) xr[u + 1] = load_x(nxt, u + 1);
+                if constexpr (S == 1) {
+                    if ((MBR_DBG & 32) == 0 && ipp == 0 && resx) xr[u + 1] = load_x(nxt, u + 1);
+                }
                 if (ok) guard.see(v);                                  // (halo lanes hold garbage that is never stored)
                 u32x4 o;
 #pragma unroll

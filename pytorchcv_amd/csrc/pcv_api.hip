@@ -668,13 +668,13 @@ static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka, 
     return nullptr;
 }
 // register-resident variant (mbr.hpp): stride 1, Cin <= 32, Cout <= 64
-struct MbrEntry { int dt, nrt, act, ro; mbconv_fn fn; };
-#define MBR_ROW(DT, NRT, ACT, RO) {DT, NRT, ACT, RO, mbr_kernel<DT, NRT, ACT, RO>},
+struct MbrEntry { int dt, nrt, act, ro, s; mbconv_fn fn; };
+#define MBR_ROW(DT, NRT, ACT, RO, S) {DT, NRT, ACT, RO, S, mbr_kernel<DT, NRT, ACT, RO, S>},
 static const MbrEntry kMbr[] = {MBR_SHAPES(MBR_ROW, PCV_BF16) MBR_SHAPES(MBR_ROW, PCV_F16)};
-static const MbrEntry* pick_mbr(int dt, int nrt, int act) {
+static const MbrEntry* pick_mbr(int dt, int nrt, int act, int stride) {
     if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
     for (const MbrEntry& e : kMbr)
-        if (e.dt == dt && e.nrt == nrt && e.act == act) return &e;
+        if (e.dt == dt && e.nrt == nrt && e.act == act && e.s == stride) return &e;
     return nullptr;
 }
 static const int kMbwMaxLds = 160 * 1024;
@@ -2138,11 +2138,12 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     int kaw = 0, nrt = 0, rbw = 0;
     const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt, &rbw);
     const bool block_shape = p.Cout <= 32 && p.Wo >= 24;
-    // register-resident tiles (mbr.hpp): stride 1, one expand K step, the unit's weights + diagonal fragments in LDS
-    if (wave_shape && ctx->use_mbr && S == 1 && kaw == 1 && nrt <= 4 && mbr_lds_layout(nrt, p.nChunks).total <= kMbwMaxLds) {
-        const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1);
+    // register-resident tiles (mbr.hpp): one expand K step, the unit's weights + diagonal fragments in LDS
+    if (wave_shape && ctx->use_mbr && kaw == 1 && nrt <= 4 && mbr_lds_layout(nrt, p.nChunks).total <= kMbwMaxLds) {
+        const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1, S);
         if (e) {
-            p.tilesH = (p.Ho + e->ro - 1) / e->ro; p.tilesW = (p.Wo + kMbrCols - 1) / kMbrCols;
+            const int oc = kMbrCols / S;                                        // output columns of a wave tile
+            p.tilesH = (p.Ho + e->ro - 1) / e->ro; p.tilesW = (p.Wo + oc - 1) / oc;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
