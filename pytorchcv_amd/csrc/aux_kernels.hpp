@@ -118,6 +118,27 @@ __global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ 
     store_elem<DT>(out, (size_t)i, w[(size_t)c * khkw + k]);
 }
 
+// depthwise 3x3, 16-bit: the packed taps [9][C] -> the compressed diagonal A fragments of the SPARSE matrix instruction
+// (v_smfmac_f32_16x16x64, csrc/mbr.hpp MmaSp: the operand layout is documented and probed there), [chunk of 32 channels][half g]
+// [filter row dy][lane] 16 B. Row i of a fragment is channel 32 c + 8 (i / 4) + 4 g + i % 4; B's lane quarter i / 4 supplies it at
+// position i % 4 of its groups gb = 0 1 2 (left, centre, right tap; group 3 is padding): slot pair m of lane (i, q) is non-zero when
+// it faces that quarter and a tap group. Built once at pack time; the fused inverted-residual kernel reads it as is.
+__global__ __launch_bounds__(256) void pack_dw_sparse_kernel(const uint16_t* __restrict__ wd, u32x4* __restrict__ table, int C, int nChunks) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nChunks * 6 * 64) return;
+    const int l = idx & 63, dy = (idx >> 6) % 3, g = ((idx >> 6) / 3) & 1, c = (idx >> 6) / 6;
+    const int i = l & 15, q = l >> 4;
+    const int ch = 32 * c + 8 * (i >> 2) + 4 * g + (i & 3);
+    u32x4 a4;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int kq = 2 * (q & 1) + (m >> 1), gb = 2 * (q >> 1) + (m & 1);
+        const uint32_t w = (kq == (i >> 2) && gb < 3 && ch < C) ? wd[(3 * dy + gb) * C + ch] : 0u;
+        a4[m] = (i & 3) == 3 ? w << 16 : w;                                         // kept positions (i % 4, 3), or (0, 3) for i % 4 == 3
+    }
+    table[idx] = a4;
+}
+
 // eval-mode BatchNorm2d (common/norm.py:34-50) folded to scale/shift, conv bias folded in
 __global__ __launch_bounds__(256) void bn_fold_kernel(int C, const float* gamma, const float* beta, const float* mean,
                                                      const float* var, float eps, const float* bias, float* scale,

@@ -32,6 +32,7 @@ struct MbParams {
     void* y;                  // [N,Ho,Wo,Cout]
     const void* w_exp;        // packed rows [round32(Cmid)][Kpad1]        (unused when EXPAND == false)
     const void* w_dw;         // [9][Cmid]
+    const void* w_dwsp;       // compressed diagonal fragments [chunk][half][filter row][lane] 16 B (pack_dw_sparse_kernel; mbr.hpp)
     const void* w_proj;       // packed rows [round32(Cout)][Kpad2]
     const float *scale_e, *shift_e, *scale_d, *shift_d, *scale_p, *shift_p;
     uint32_t x_bytes, y_bytes, wexp_bytes, wdw_bytes, wproj_bytes;

@@ -37,15 +37,18 @@
 #include "mbw.hpp"            // mbw_swz, mbw_act
 
 struct MbrLds {
-    int wexp, wproj, af, wdw, bn, bnp, total;
+    int wexp, wproj, af, bn, bnp, total;
 };
-static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks) {
+// ka: K steps of the expand GEMM (Cin <= 32 ka); afl: the compressed depthwise fragments live in LDS too (else every wave reads its
+// three fragments per half-chunk from the packed table in L2: units whose 6 KB per chunk do not fit)
+// wel: the expand weights live in LDS (else every wave reads its fragments from L2 per half-chunk, one pass ahead: the 96 -> 576 -> 96
+// units, whose two 1x1 matrices are 216 KB)
+static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks, int ka, bool afl, bool wel = true) {
     MbrLds L;
     int o = 0;
-    L.wexp = o; o += nChunks * 32 * 64;                 // [chunk][32 rows][64 B]
+    L.wexp = o; o += wel ? nChunks * ka * 32 * 64 : 0;  // [chunk][K step][32 rows][64 B]
     L.wproj = o; o += nChunks * nrt * 16 * 64;          // [chunk][nrt * 16 rows][64 B]
-    L.af = o; o += nChunks * 6 * 1024;                  // [chunk][half g][filter row][lane] 16 B: compressed diagonal depthwise fragments
-    L.wdw = o; o += nChunks * 16 * 64;                  // [chunk][tap (9 of 16)][32 ch] 16-bit: staging for the fragment build
+    L.af = o; o += afl ? nChunks * 6 * 1024 : 0;        // [chunk][half g][filter row][lane] 16 B: compressed diagonal depthwise fragments
     L.bn = o; o += nChunks * 4 * 32 * 4;                // [chunk][scale_e, shift_e, scale_d, shift_d][32 ch] fp32
     L.bnp = o; o += 2 * nrt * 16 * 4;                   // scale_p, shift_p
     L.total = o;
@@ -96,10 +99,13 @@ template <int CTRL> __device__ __forceinline__ uint32_t mbr_dpp(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);      // bound_ctrl: lanes shifted in read 0
 }
 
-// NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: Cout <= 64); ACT: activation of the expand and depthwise stages when both
-// are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; RO: output rows of a wave tile. Stride 1, Cin <= 32. blockDim.x = 512.
-template <int DT, int NRT, int ACT, int RO, int S = 1>
-__global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
+// NRT: 16-row tiles of the project GEMM (2: Cout <= 32, 4: <= 64, 6: <= 96); ACT: activation of the expand and depthwise stages when
+// both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; RO: output rows of a wave tile; S: stride; KA: K steps of the expand GEMM
+// (Cin <= 32 KA); AFL: depthwise fragments in LDS (else read from the packed table per half-chunk); WAVES: waves per block (8: two per
+// SIMD at 256 registers; 4: one per SIMD with the 512-register budget, for the units whose accumulators + x fragments need it);
+// WEL: expand weights in LDS. blockDim.x = 64 WAVES.
+template <int DT, int NRT, int ACT, int RO, int S = 1, int KA = 1, bool AFL = true, int WAVES = 8, bool WEL = true>
+__global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // Stride 2 keeps the window layout (16 consecutive input columns per lane row, so the taps of the output centred on lane l are
     // still lanes l - 1, l, l + 1): the depthwise stage runs on every lane, the outputs are the 7 odd lanes 1 .. 13 (input columns
@@ -117,7 +123,10 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
     if constexpr (FAST) __builtin_amdgcn_s_setreg(1 | (8 << 6), 0);      // MODE.DX10_CLAMP = 0: the clamp modifier passes NaN through (as torch's hardtanh)
     typedef typename Mma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MbrLds L = mbr_lds_layout(NRT, p.nChunks);
+    const MbrLds L = mbr_lds_layout(NRT, p.nChunks, KA, AFL, WEL);
+    // fragments that come from L2 are requested one half-chunk pass ahead into the other of two register sets (only where the registers
+    // exist: the one-wave-per-SIMD form)
+    constexpr bool PF = WAVES == 4 && (!WEL || !AFL);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,12 +148,12 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
 
     // ---- the unit's weights and BN constants -> LDS, once per block -------------------------------------------------------------------
     // ONE loop over every 16-byte piece of the five tables, four independent loads in flight per thread: as five loops of
-    // load -> store the prologue measured 10 K cycles (every iteration a full L2 latency, the fragment build two dependent 2-byte
-    // loads per entry), 4 - 14 % of a launch. Pieces beyond a table's end (padded rows / channels) are stored as zeros.
+    // load -> store the prologue measured 10 K cycles (every iteration a full L2 latency), 4 - 14 % of a launch. Pieces beyond a
+    // table's end (padded rows / channels) are stored as zeros. The depthwise fragments come ready-made from the packed blob
+    // (pack_dw_sparse_kernel, aux_kernels.hpp).
     {
-        const int nA = p.nChunks * 128, nB = p.nChunks * NRT * 64, nC = p.nChunks * 64, nD = p.nChunks * 32, nE = 8 * NRT;
+        const int nA = WEL ? p.nChunks * KA * 128 : 0, nB = p.nChunks * NRT * 64, nC = AFL ? p.nChunks * 6 * 64 : 0, nD = p.nChunks * 32, nE = 8 * NRT;
         const int total = nA + nB + nC + nD + nE;
-        char* const Wds = smem + L.wdw;
         for (int base = tid; base < total; base += 4 * blockDim.x) {
             u32x4 v[4];
             float fold[4];
@@ -155,20 +164,19 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                 const char* src = nullptr;
                 bool ok = false;
                 dst[k] = nullptr;
-                if (i < nA) {                                                      // expand weights: row = 32 c + r in MFMA order
-                    const int slot = i & 3, row = i >> 2;
-                    const uint32_t off = (uint32_t)((row * p.Kpad1 + 8 * slot) * 2);
+                if (i < nA) {                                                      // expand weights: rows 32 c + r in MFMA order, K step ks
+                    const int slot = i & 3, r = (i >> 2) & 31, ks = (i >> 7) % KA, c = (i >> 7) / KA;
+                    const uint32_t off = (uint32_t)(((32 * c + r) * p.Kpad1 + 32 * ks + 8 * slot) * 2);
                     src = static_cast<const char*>(p.w_exp) + off; ok = off + 16u <= p.wexp_bytes;
-                    dst[k] = Wes + row * 64 + ((slot ^ mbw_swz<true>(row)) << 4);
+                    dst[k] = Wes + ((c * KA + ks) * 32 + r) * 64 + ((slot ^ mbw_swz<true>(r)) << 4);
                 } else if ((i -= nA) < nB) {                                       // projection weights: K slice 32 c of every row
                     const int slot = i & 3, row = (i >> 2) % (NRT * 16), c = (i >> 2) / (NRT * 16);
                     const uint32_t off = (uint32_t)((row * p.Kpad2 + 32 * c + 8 * slot) * 2);
                     src = static_cast<const char*>(p.w_proj) + off; ok = off + 16u <= p.wproj_bytes;
                     dst[k] = Wps + (c * NRT * 16 + row) * 64 + ((slot ^ mbw_swz<true>(row)) << 4);
-                } else if ((i -= nB) < nC) {                                       // depthwise taps [9][Cmid] -> [chunk][tap][32]
-                    const int pc = i & 3, t = (i >> 2) & 15, ch = 32 * (i >> 6) + 8 * pc;
-                    src = static_cast<const char*>(p.w_dw) + (t * p.Cmid + ch) * 2; ok = t < 9 && ch < p.Cmid;
-                    dst[k] = Wds + i * 16;
+                } else if ((i -= nB) < nC) {                                       // compressed depthwise fragments, as packed
+                    src = static_cast<const char*>(p.w_dwsp) + i * 16; ok = true;
+                    dst[k] = Afs + i * 16;
                 } else if ((i -= nC) < nD) {                                       // BN of the expand / depthwise stages -> [chunk][which][32]
                     const int pc = i & 7, which = (i >> 3) & 3, ch = 32 * (i >> 5) + 4 * pc;
                     const float* arr = which == 0 ? p.scale_e : which == 1 ? p.shift_e : which == 2 ? p.scale_d : p.shift_d;
@@ -195,27 +203,8 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                 if (dst[k] != nullptr) *reinterpret_cast<u32x4*>(dst[k]) = v[k];
             }
         }
-        __syncthreads();
-        // compressed diagonal depthwise fragments (MmaSp): A lane (row i, quarter q) of (chunk c, half g, filter row dy). Row i is channel
-        // 32 c + 8 (i / 4) + 4 g + i % 4, which B's lane quarter i / 4 supplies at position i % 4 of its groups gb = 0 1 2 (left, centre,
-        // right tap; group 3 is padding): slot pair m of this lane is non-zero when it faces that quarter and a tap group.
-        const uint16_t* const wd = reinterpret_cast<const uint16_t*>(Wds);
-#pragma unroll 4
-        for (int idx = tid; idx < p.nChunks * 6 * 64; idx += blockDim.x) {
-            const int l = idx & 63, dy = (idx >> 6) % 3, g = ((idx >> 6) / 3) & 1, c = (idx >> 6) / 6;
-            const int i = l & 15, q = l >> 4;
-            const int chl = 8 * (i >> 2) + 4 * g + (i & 3);                          // channel inside the chunk
-            u32x4 a4;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int kq = 2 * (q & 1) + (m >> 1), gb = 2 * (q >> 1) + (m & 1);
-                const uint32_t w = (kq == (i >> 2) && gb < 3) ? wd[(c * 16 + 3 * dy + gb) * 32 + chl] : 0u;
-                a4[m] = (i & 3) == 3 ? w << 16 : w;                                 // positions (i % 4, 3), or (0, 3) for i % 4 == 3: see spidx
-            }
-            *reinterpret_cast<u32x4*>(Afs + (size_t)idx * 16) = a4;
-        }
     }
-    __syncthreads();
+    __syncthreads();                                                               // the only barrier of the kernel
 
 #ifdef MBR_CYCLES
     k1__ = __builtin_amdgcn_s_memtime();
@@ -226,13 +215,15 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
     const char* const we_rd = Wes + fr * 64 + fsw;
     const char* const wp_rd = Wps + fr * 64 + fsw;
     const char* const af_rd = Afs + lane * 16;
+    const __amdgpu_buffer_rsrc_t wersrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_exp), 0, p.wexp_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t afrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w_dwsp), 0, (uint32_t)(p.nChunks * 6 * 1024), 0x00020000);
     // sparse index of this lane's A rows (MmaSp): every group keeps positions (i % 4, 3) - the weight in the pair's first slot, a zero in
     // the second - or (0, 3) with the weight second for i % 4 == 3; all eight 4-bit fields alike
     const int spidx = (((fr & 3) == 3 ? 0 : (fr & 3)) | (3 << 2)) * 0x11111111;
 
     const int nWavesAll = gridDim.x * nWaves;
     int tile = blockIdx.x * nWaves + wave;
-    const bool resx = S == 1 && NRT == 2 && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
+    const bool resx = S == 1 && NRT == 2 * KA && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
 
     // A tile's position, decoded ONCE (three scalar divisions; decoded inside every row load the epilogue's prefetch alone was ~700
     // scalar instructions per tile): image, first output row, this lane's window column and the byte offset of its pixel in window row 0
@@ -245,22 +236,40 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
         T.n = t2 / p.tilesH;
         T.h0 = th * RO;                                                             // first OUTPUT row
         T.wi = tw * OC * S - 1 + fr;                                                // this lane's INPUT column
-        T.colok = (t < p.nTiles) & ((unsigned)T.wi < (unsigned)p.W) & (8 * fq < p.Cin);
+        T.colok = (t < p.nTiles) & ((unsigned)T.wi < (unsigned)p.W);
         T.off0 = (((T.n * p.H + T.h0 * S - 1) * p.W + T.wi) * p.Cin + 8 * fq) * 2;                          // < 2 GiB: checked by the host
         return T;
     };
     const int rowpitch = p.W * p.Cin * 2;
     // x fragment of window row r (window rows h0 - 1 .. h0 + RO, columns w0 - 1 .. w0 + 14)
-    auto load_x = [&](const TilePos& T, int r) __attribute__((always_inline)) -> u32x4 {
-        const bool ok = T.colok & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H);
-        return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 + r * rowpitch) : 0x80000000u, 0, 0);
+    auto load_x = [&](const TilePos& T, int r, int ks) __attribute__((always_inline)) -> u32x4 {
+        const bool ok = T.colok & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H) & (32 * ks + 8 * fq < p.Cin);
+        return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 + r * rowpitch + 64 * ks) : 0x80000000u, 0, 0);
     };
 
+    // fragments of half-chunk pass h = 2 c + g that do not live in LDS
+    auto fetch_we = [&](int h, frag (&w)[KA]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KA; ++ks)
+            w[ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(wersrc, (uint32_t)(((16 * h + fr) * p.Kpad1 + 32 * ks + 8 * fq) * 2), 0, 0));
+    };
+    auto fetch_af = [&](int h, frag (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(afrsrc, (uint32_t)(((h * 3 + j) * 64 + lane) * 16), 0, 0));
+    };
+    frag weG[PF ? 2 : 1][KA], afG[PF ? 2 : 1][3];
+    if constexpr (PF) {
+        if constexpr (!WEL) fetch_we(0, weG[0]);
+        if constexpr (!AFL) fetch_af(0, afG[0]);
+    }
+
     TilePos cur = decode(tile);
-    u32x4 xr[NR];
+    u32x4 xr[NR][KA];
     if (tile < p.nTiles) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) xr[r] = load_x(cur, r);
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(cur, r, ks);
     }
 
     while (tile < p.nTiles) {
@@ -291,10 +300,24 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
             // fragments, one expand fragment and one half's BN constants (both halves at once spilled: 256 registers).
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                frag af[3];
-                const frag we = *reinterpret_cast<const frag*>(we_rd + (32 * c + 16 * g) * 64);
+                frag af[3], we[KA];
+                if constexpr (PF) {                                     // this pass from set g, the next pass (the next tile's first behind the last) into set g ^ 1
+                    const int hn = (2 * c + g + 1 == 2 * p.nChunks) ? 0 : 2 * c + g + 1;
+                    if constexpr (!WEL) fetch_we(hn, weG[g ^ 1]);
+                    if constexpr (!AFL) fetch_af(hn, afG[g ^ 1]);
+                }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) af[j] = *reinterpret_cast<const frag*>(af_rd + ((c * 2 + g) * 3 + j) * 1024);
+                for (int ks = 0; ks < KA; ++ks) {
+                    if constexpr (WEL) we[ks] = *reinterpret_cast<const frag*>(we_rd + ((c * KA + ks) * 32 + 16 * g) * 64);
+                    else if constexpr (PF) we[ks] = weG[g][ks];
+                }
+                if constexpr (!WEL && !PF) fetch_we(2 * c + g, we);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (AFL) af[j] = *reinterpret_cast<const frag*>(af_rd + ((c * 2 + g) * 3 + j) * 1024);
+                    else if constexpr (PF) af[j] = afG[g][j];
+                }
+                if constexpr (!AFL && !PF) fetch_af(2 * c + g, af);
                 // BN constants of this lane's 4 channels 32 c + 8 fq + 4 g + e: the same channels in S1 (accumulator rows) and S2
                 f32x4 se = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 8 * fq + 4 * g);
                 f32x4 he = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 32 + 8 * fq + 4 * g);
@@ -323,9 +346,14 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                     // ---- S1: window row r of the E half-chunk ----------------------------------------------------------------------
                     u32x8 b8;
                     {
-                        const f32x4 e0 = Mma<DT>::run(we, __builtin_bit_cast(frag, xr[r]), (f32x4){0.f, 0.f, 0.f, 0.f});
-                        // the next tile's row into the register this S1 used last (rows that are the unit's skip tensor: behind the epilogue)
-                        if ((MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) xr[r] = load_x(nxt, r);
+                        f32x4 e0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KA; ++ks) e0 = Mma<DT>::run(we[ks], __builtin_bit_cast(frag, xr[r][ks]), e0);
+                        // the next tile's row into the registers this S1 used last (rows that are the unit's skip tensor: behind the epilogue)
+                        if ((MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) {
+#pragma unroll
+                            for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(nxt, r, ks);
+                        }
                         uint32_t o[2];
                         if constexpr (FAST) {
                             const uint32_t rowmask = (unsigned)(h0 * S - 1 + r) < (unsigned)p.H ? 0xFFFFFFFFu : 0u;      // (scalar) rows outside the image
@@ -442,8 +470,8 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                     v[4 + e] = acc[2 * ipp + 1][u][e] * sp[1][e] + hp[1][e];
                 }
                 if constexpr (!decltype(plain)::value) apply_act8(v, act_p);
-                if (p.res != nullptr && ipp == 0) {                      // (a skip tensor implies Cout == Cin <= 32: one channel pair of tiles)
-                    const u32x4 r4 = resx ? xr[S == 1 ? u + 1 : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                if (p.res != nullptr) {                                  // (x as the skip tensor: channels 32 ipp + 8 fq = K step ipp of window row u + 1)
+                    const u32x4 r4 = resx ? xr[S == 1 ? u + 1 : 0][ipp < KA ? ipp : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float r0, r1;
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(512) void mbr_kernel(const MbParams p) {
                     if constexpr (!decltype(plain)::value) apply_act8(v, post);
                 }
                 if constexpr (S == 1) {
-                    if ((MBR_DBG & 32) == 0 && ipp == 0 && resx) xr[u + 1] = load_x(nxt, u + 1);
+                    if ((MBR_DBG & 32) == 0 && resx && ipp < KA) xr[u + 1][ipp] = load_x(nxt, u + 1, ipp);
                 }
                 if (ok) guard.see(v);                                  // (halo lanes hold garbage that is never stored)
                 u32x4 o;

@@ -668,13 +668,16 @@ static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka, 
     return nullptr;
 }
 // register-resident variant (mbr.hpp): stride 1, Cin <= 32, Cout <= 64
-struct MbrEntry { int dt, nrt, act, ro, s; mbconv_fn fn; };
-#define MBR_ROW(DT, NRT, ACT, RO, S) {DT, NRT, ACT, RO, S, mbr_kernel<DT, NRT, ACT, RO, S>},
+struct MbrEntry { int dt, nrt, act, ro, s, ka; bool afl; int waves; bool wel; mbconv_fn fn; };
+#define MBR_ROW(DT, NRT, ACT, RO, S, KA, AFL, WV, WEL) {DT, NRT, ACT, RO, S, KA, AFL, WV, WEL, mbr_kernel<DT, NRT, ACT, RO, S, KA, AFL, WV, WEL>},
 static const MbrEntry kMbr[] = {MBR_SHAPES(MBR_ROW, PCV_BF16) MBR_SHAPES(MBR_ROW, PCV_F16)};
-static const MbrEntry* pick_mbr(int dt, int nrt, int act, int stride) {
+// the instantiation for a unit, when its tables fit the LDS
+static const MbrEntry* pick_mbr(int dt, int nrt, int act, int stride, int ka, int nChunks) {
     if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
     for (const MbrEntry& e : kMbr)
-        if (e.dt == dt && e.nrt == nrt && e.act == act && e.s == stride) return &e;
+        if (e.dt == dt && e.nrt == nrt && e.act == act && e.s == stride && e.ka == ka &&
+            mbr_lds_layout(nrt, nChunks, ka, e.afl, e.wel).total <= 160 * 1024)
+            return &e;
     return nullptr;
 }
 static const int kMbwMaxLds = 160 * 1024;
@@ -1114,9 +1117,15 @@ static const char* check_dw(const pcv_conv_desc& d) {
     return nullptr;
 }
 
+// packed depthwise blob: the taps [kh * kw][C] (what the depthwise kernels read), then - 16-bit 3x3 only - the compressed diagonal
+// fragments of the sparse matrix instruction for the fused inverted-residual kernel (pack_dw_sparse_kernel, csrc/mbr.hpp)
+static size_t dw_taps_bytes(const pcv_conv_desc& d) { return (((size_t)d.kh * d.kw * d.Cin * esize(d.dtype)) + 15) & ~(size_t)15; }
+static size_t dw_sparse_bytes(const pcv_conv_desc& d) {
+    return (d.kh == 3 && d.dtype != PCV_F32) ? (size_t)((d.Cin + 31) / 32) * 6 * 1024 : 0;
+}
 int pcv_dwconv_packed_bytes(const pcv_conv_desc* d, size_t* bytes) {
     if (!d || !bytes || check_dw(*d)) return PCV_ERR_INVALID;
-    *bytes = (size_t)d->kh * d->kw * d->Cin * esize(d->dtype);
+    *bytes = dw_taps_bytes(*d) + dw_sparse_bytes(*d);
     return PCV_OK;
 }
 
@@ -1132,6 +1141,11 @@ int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* 
     if (d->dtype == PCV_BF16) pack_dw_kernel<PCV_BF16><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
     else if (d->dtype == PCV_F16) pack_dw_kernel<PCV_F16><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
     else pack_dw_kernel<PCV_F32><<<grid, 256, 0, s>>>(w, packed, d->Cin, d->kh * d->kw);
+    if (dw_sparse_bytes(*d) != 0) {
+        const int nChunks = (d->Cin + 31) / 32;
+        pack_dw_sparse_kernel<<<(unsigned)((nChunks * 6 * 64 + 255) / 256), 256, 0, s>>>(
+            static_cast<const uint16_t*>(packed), reinterpret_cast<u32x4*>(static_cast<char*>(packed) + dw_taps_bytes(*d)), d->Cin, nChunks);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return PCV_OK;
 }
@@ -2115,6 +2129,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     p.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);
     p.w_exp = d_exp ? static_cast<const char*>(packed_exp) + Pe.ktab_bytes : nullptr;
     p.w_dw = packed_dw;
+    p.w_dwsp = static_cast<const char*>(packed_dw) + dw_taps_bytes(*d_dw);                // (present for 16-bit 3x3: checked by mbconv_unsupported)
     p.w_proj = static_cast<const char*>(packed_proj) + Pp.ktab_bytes;
     p.scale_e = scale_e; p.shift_e = shift_e; p.scale_d = scale_d; p.shift_d = shift_d; p.scale_p = scale_p; p.shift_p = shift_p;
     p.N = d_dw->N; p.H = d_dw->H; p.W = d_dw->W; p.Cmid = d_dw->Cin; p.Cin = d_exp ? d_exp->Cin : p.Cmid; p.Cout = d_proj->Cout;
@@ -2139,16 +2154,16 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     const bool wave_shape = d_exp && mbw_shape(p.Cin, p.Cout, S, p.H, p.W, &kaw, &nrt, &rbw);
     const bool block_shape = p.Cout <= 32 && p.Wo >= 24;
     // register-resident tiles (mbr.hpp): one expand K step, the unit's weights + diagonal fragments in LDS
-    if (wave_shape && ctx->use_mbr && kaw == 1 && nrt <= 4 && mbr_lds_layout(nrt, p.nChunks).total <= kMbwMaxLds) {
-        const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1, S);
+    if (wave_shape && ctx->use_mbr) {
+        const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1, S, kaw, p.nChunks);
         if (e) {
             const int oc = kMbrCols / S;                                        // output columns of a wave tile
             p.tilesH = (p.Ho + e->ro - 1) / e->ro; p.tilesW = (p.Wo + oc - 1) / oc;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
-            const unsigned gridr = (unsigned)std::min<long>((nT + 7) / 8, (long)block_slots(ctx, 1));
-            hipLaunchKernelGGL(e->fn, dim3(gridr), dim3(512), mbr_lds_layout(nrt, p.nChunks).total, (hipStream_t)stream, p);
+            const unsigned gridr = (unsigned)std::min<long>((nT + e->waves - 1) / e->waves, (long)block_slots(ctx, 1));
+            hipLaunchKernelGGL(e->fn, dim3(gridr), dim3(64 * e->waves), mbr_lds_layout(nrt, p.nChunks, kaw, e->afl, e->wel).total, (hipStream_t)stream, p);
             HIP_TRY(ctx, hipGetLastError());
             return PCV_OK;
         }
