@@ -49,12 +49,13 @@ WORKLOADS = {
 OTHER_CONFIGS = ("mobilenetv2_w1_bs512", "resnext101_32x4d_bs256")      # BASELINE.json configs[2], configs[3]
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0         # HBM3E spec peak, MI355X_MICROARCH.md "HBM3E peak BW"
+TERM_GRACE_S = 10.0                       # launcher: seconds between SIGTERM and SIGKILL for ranks that do not exit
+OTHER_STEPS, OTHER_WARMUP = 30, 5          # timed / warm-up steps of each `other_configs` workload (r4: 10 steps = 17 ms was too short a window)
 RIDGE_FLOP_PER_BYTE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)     # 312.5: a class above it is MFMA-bound, below it HBM-bound
 
 # Kernel classes. Live timing classifies a launch by what the host asked for; the rocprofv3 / PMC summaries classify a dispatch
 # by its kernel name (`kernel_class_of`, also used by tests/tools/*). The two agree except where the library routes a shape to
 # another kernel family than the rule below assumes (d3q's 1x1 mode is chosen by tile count as well as by channels).
-CLASS_BOUND = {"dense3x3": "mfma", "dense1x1_kheavy": "mfma"}           # everything else: "hbm"
 
 
 def kernel_class_of(name: str):
@@ -551,8 +552,13 @@ def compact_roofline(roof):
     """The north-star class of a workload, as it goes into `other_configs`."""
     if roof is None:
         return None
-    return {k: roof.get(k) for k in ("kernel_class", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
-                                     "traffic", "rocprof_avg_launch_us", "rocprof_frac")}
+    out = {k: roof.get(k) for k in ("kernel_class", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                    "traffic", "rocprof_avg_launch_us", "rocprof_frac")}
+    # every class of the step beside it (VERDICT r4 item 8: MobileNetV2's fused units hold 13 of its 17 depthwise layers and most of its time)
+    out["classes"] = [{k: e.get(k) for k in ("kernel_class", "launches_per_step", "us_per_step", "share_of_conv_time", "bound", "frac",
+                                             "frac_of_hbm_peak", "frac_of_mfma_peak", "rocprof_frac", "traffic_mb_per_launch")}
+                      for e in roof.get("classes", [])]
+    return out
 
 
 def roofline_of(env, workload, ctx, passes):
@@ -573,11 +579,14 @@ def roofline_of(env, workload, ctx, passes):
 
     def entry(k, c, detail):
         intensity = c["gflop_per_launch"] * 1e9 / (c["mb_per_launch"] * 1e6)
-        bound = CLASS_BOUND.get(k, "hbm")
+        # the roof that bounds a class is read off its arithmetic intensity against the ridge (312.5 FLOP/B), not assumed per class
+        # (the K-heavy 1x1 layers sit at 136 FLOP/B - HBM-bound); both fractions are printed
+        bound = "mfma" if intensity >= RIDGE_FLOP_PER_BYTE else "hbm"
         e = dict(kernel_class=k, bound=bound, launches_per_step=c["launches_per_step"], us_per_step=round(c["us_per_step"], 1),
                  share_of_conv_time=round(c["us_per_step"] / total_us, 3), avg_launch_us=round(c["avg_launch_us"], 2),
                  achieved=round(c["tflops"], 1) if bound == "mfma" else round(c["gbs"], 1), unit="TFLOP/s" if bound == "mfma" else "GB/s",
                  frac=round(c["tflops"] / MFMA_PEAK_TFLOPS if bound == "mfma" else c["gbs"] / HBM_PEAK_GBS, 4),
+                 frac_of_mfma_peak=round(c["tflops"] / MFMA_PEAK_TFLOPS, 4), frac_of_hbm_peak=round(c["gbs"] / HBM_PEAK_GBS, 4),
                  tflops=round(c["tflops"], 1), gbs=round(c["gbs"], 1), flop_per_byte=round(intensity, 1),
                  algorithmic_gflop_per_launch=round(c["gflop_per_launch"], 3), algorithmic_mb_per_launch=round(c["mb_per_launch"], 3),
                  rocprof_avg_launch_us=prof.get(k, {}).get("avg_us"), rocprof_calls=prof.get(k, {}).get("calls"),
@@ -660,17 +669,25 @@ def launch_ranks(n, argv, stub):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
     worst, line = 0, None
+    term_at = None                                                    # when SIGTERM went out: SIGKILL after a grace period, then stop waiting
     try:
         pending = set(range(n))
         while pending:
-            if time.time() - t_start > limit:
+            if term_at is None and time.time() - t_start > limit:
                 print("bench.py: ranks {} still running after {:.0f} s (PCV_BENCH_TIMEOUT_S): terminating them".format(sorted(pending), limit),
                       file=sys.stderr)
                 for o in pending:
                     killed.add(o)
                     procs[o].terminate()
                 worst = worst or 124
-                limit = float("inf")
+                term_at = time.time()
+            if term_at is not None and time.time() - term_at > TERM_GRACE_S:
+                # a rank that ignores SIGTERM (stuck in a driver call, a library handler): kill it and stop waiting - the launcher
+                # always returns
+                print("bench.py: ranks {} ignored SIGTERM for {:.0f} s: killing them".format(sorted(pending), TERM_GRACE_S), file=sys.stderr)
+                for o in pending:
+                    procs[o].kill()
+                break
             for r in sorted(pending):
                 rc = procs[r].poll()
                 if rc is None:
@@ -681,6 +698,7 @@ def launch_ranks(n, argv, stub):
                     for o in pending:                                 # exact children only; their exit codes are ours, not theirs
                         killed.add(o)
                         procs[o].terminate()
+                    term_at = term_at or time.time()
             time.sleep(0.05)
         out0.seek(0)
         for ln in out0.read().splitlines():
@@ -760,8 +778,8 @@ def main(argv=None):
         torch.cuda.empty_cache()
         others = {}
         for w in OTHER_CONFIGS:
-            r, c = run_workload(env, w, args, 10, 3)
-            others[w] = dict(value=r["value"], unit="images/sec", ms_per_step=r["ms_per_step"], steps=10, warmup=3, dtype=r["dtype"],
+            r, c = run_workload(env, w, args, OTHER_STEPS, OTHER_WARMUP)
+            others[w] = dict(value=r["value"], unit="images/sec", ms_per_step=r["ms_per_step"], steps=OTHER_STEPS, warmup=OTHER_WARMUP, dtype=r["dtype"],
                              launch=r["launch"], rows_checked="every row of the timed batch equals the 8-image eager forward bit for bit",
                              roofline=compact_roofline(roofline_of(env, w, c, 3)), latency=forward_latency(c, samples=20))
             del r, c

@@ -319,9 +319,12 @@ __device__ __forceinline__ void d3c_body(const D3Params& p, char* smem) {
 #ifdef D3C_CYCLES
             if (stamp__) c2__ = c1__ = __builtin_amdgcn_s_memtime();
 #endif
-            // the next patch has landed (behind its last piece, step 114, only the last block's store - and, with a skip tensor, its long
-            // consumed residual load - were issued); every wave is done with this patch
-            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            // the next patch has landed: behind its last piece (step 114) exactly two stores were issued - block 5's at step 6 x 18 + 15 =
+            // 123 and the last block's behind the loop (with a skip tensor the residual loads went out in FRONT of the pieces) - so
+            // vmcnt(2) waits for the piece and for neither store (vmcnt(1) also waited for block 5's HBM store, per tile);
+            // every wave is done with this patch
+            static_assert(114 > 5 * 18 + 15 && 114 < 6 * 18 + 15, "exactly two stores (blocks 5 and 6) are issued behind the last DMA piece");
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             d3q_sync();
 #ifdef D3C_CYCLES
             if (stamp__ && lane == 0) {

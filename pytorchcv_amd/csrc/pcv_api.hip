@@ -1448,6 +1448,8 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     q.div_hw = make_fastdiv((uint32_t)q.HW);
     q.act = d->act; q.post_act = d->post_act;
     q.nChTiles = (d->Cout + S.BM - 1) / S.BM;
+    // (c64 covers both register-weight kernels: d3c tiles D3CCfg::ROWS image rows, d3k D3KCfg::ROWS - route_conv counts with each one's own)
+    static_assert(D3CCfg::ROWS == D3KCfg::ROWS, "launch_d3q computes the tile count of d3c AND d3k from one ROWS constant");
     const long long nT = c64 ? (long long)d->N * ((d->H + D3CCfg::ROWS - 1) / D3CCfg::ROWS) * q.nChTiles
                              : ((long long)((G.M64 + S.BP - 1) / S.BP)) * q.nChTiles;
     if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
