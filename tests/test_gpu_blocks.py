@@ -659,6 +659,55 @@ def test_conv3x3_c128_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
+_RW_KERNELS = {  # kernel -> (ConvBlock factory name, input channels, H, W, tuning key that forces it, tuning that gives the generic kernel)
+    "d3c": ("conv3x3_block", 64, 12, 56, "d3c", {"d3x3": 0}),
+    "d3k": ("conv3x3_block", 128, 12, 28, "d3k", {"d3x3": 0}),
+    "p1r": ("conv1x1_block", 512, 14, 14, "p1r", {"d1x1": 0}),
+    "p1r256": ("conv1x1_block", 256, 14, 14, "p1r", {"d1x1": 0}),
+}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("variant", ["none+res", "relu6", "relu6+res+relu6", "none+res+relu", "concat", "concat+res"])
+@pytest.mark.parametrize("kernel", sorted(_RW_KERNELS))
+def test_register_weight_kernels_epilogue_variants_equal_generic(kernel, variant, dtype, cuda_device):
+    """The epilogue forms of the register-weight kernels (d3c / d3k / p1r) that the ReLU-only shape sweeps above never run on their own
+    (ADVICE r4): no activation + skip tensor (the real bottleneck conv3 form, p1r MODE 1), the ReLU6 upper clamps (ahi / phi, p1r MODE 4),
+    activation in front of AND behind the skip add, and stores into a channel slice of a wider tensor (y_cpitch > Cout: `out=`) -
+    each bit for bit against the generic implicit-GEMM kernel."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common import conv as convmod
+    from pytorchcv_amd.models.common.activ import create_activation_layer
+    ctor, C, H, W, key, generic = _RW_KERNELS[kernel]
+    Cout = 256 if kernel.startswith("p1r") else C
+    act = "relu6" if variant.startswith("relu6") else None if variant.startswith("none") else "relu"
+    use_res = "+res" in variant
+    post = {"relu6+res+relu6": torch.nn.ReLU6(), "none+res+relu": torch.nn.ReLU()}.get(variant)
+    blk = getattr(convmod, ctor)(in_channels=C, out_channels=Cout, activation=(lambda: create_activation_layer(act)) if act else None).eval()
+    blk.load_state_dict(util.synth_state_dict(blk.state_dict(), seed=91))
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    N = 5
+    x = util.synth_input(N, C, H, W, seed=41)
+    res = util.synth_input(N, Cout, H, W, seed=42) if use_res else None
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+
+    def run(tune):
+        with torch.no_grad(), util.tuning(**tune):
+            xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+            rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+            if variant.startswith("concat"):
+                buf = torch.full((N, H, W, Cout + 72), 7.0, dtype=tdt, device=cuda_device)
+                assert blk(xh, residual=rh, out=(buf, 40)) is None
+                return buf
+            return blk(xh, residual=rh, post_act=post).t
+    y_k, y_g = run({key: 1}), run(generic)
+    torch.cuda.synchronize()
+    assert torch.equal(y_k, y_g), "{} {}: {} elements differ from the generic kernel".format(kernel, variant, int((y_k != y_g).sum()))
+    if variant.startswith("concat"):
+        assert bool((y_k[..., :40] == 7.0).all()) and bool((y_k[..., 40 + Cout:] == 7.0).all()), "wrote outside its channel slice"
+
+
 _D1_SHAPES = [  # (N, Cin, Cout, H, W, residual[, stride]): K-heavy pointwise layers (csrc/d3q_conv.hpp, 1x1 mode)
     (16, 1024, 512, 14, 14, False), (16, 512, 1024, 14, 14, True), (9, 2048, 512, 7, 7, False), (5, 512, 2048, 7, 7, True),
     (3, 576, 136, 13, 11, False), (2, 64, 256, 20, 20, True), (1, 192, 72, 5, 9, False),
