@@ -37,13 +37,14 @@
 #include "mbw.hpp"            // mbw_swz, mbw_act
 
 struct MbrLds {
-    int wexp, wproj, af, bn, bnp, total;
+    int wexp, wproj, af, bn, bnp, xs, total;
 };
 // ka: K steps of the expand GEMM (Cin <= 32 ka); afl: the compressed depthwise fragments live in LDS too (else every wave reads its
 // three fragments per half-chunk from the packed table in L2: units whose 6 KB per chunk do not fit)
 // wel: the expand weights live in LDS (else every wave reads its fragments from L2 per half-chunk, one pass ahead: the 96 -> 576 -> 96
 // units, whose two 1x1 matrices are 216 KB)
-static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks, int ka, bool afl, bool wel = true) {
+// xrows: window rows of a wave tile when x is staged through LDS (two buffers per wave, XL below), else 0
+static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks, int ka, bool afl, bool wel = true, int xrows = 0, int waves = 8) {
     MbrLds L;
     int o = 0;
     L.wexp = o; o += wel ? nChunks * ka * 32 * 64 : 0;  // [chunk][K step][32 rows][64 B]
@@ -51,6 +52,7 @@ static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks, in
     L.af = o; o += afl ? nChunks * 6 * 1024 : 0;        // [chunk][half g][filter row][lane] 16 B: compressed diagonal depthwise fragments
     L.bn = o; o += nChunks * 4 * 32 * 4;                // [chunk][scale_e, shift_e, scale_d, shift_d][32 ch] fp32
     L.bnp = o; o += 2 * nrt * 16 * 4;                   // scale_p, shift_p
+    L.xs = o; o += waves * 2 * xrows * 1024;            // [wave][buffer][window row][lane] 16 B
     L.total = o;
     return L;
 }
@@ -103,8 +105,10 @@ template <int CTRL> __device__ __forceinline__ uint32_t mbr_dpp(uint32_t v) {
 // both are ReLU or both ReLU6, -1 = read p.act_e / p.act_d; RO: output rows of a wave tile; S: stride; KA: K steps of the expand GEMM
 // (Cin <= 32 KA); AFL: depthwise fragments in LDS (else read from the packed table per half-chunk); WAVES: waves per block (8: two per
 // SIMD at 256 registers; 4: one per SIMD with the 512-register budget, for the units whose accumulators + x fragments need it);
-// WEL: expand weights in LDS. blockDim.x = 64 WAVES.
-template <int DT, int NRT, int ACT, int RO, int S = 1, int KA = 1, bool AFL = true, int WAVES = 8, bool WEL = true>
+// WEL: expand weights in LDS; XL: the x window goes global -> LDS by LDS-DMA, a whole tile ahead, into one of two wave-private buffers
+// (units with so few chunks that the register form's prefetch - issued inside the last chunk - arrives late: 32 -> 32 -> 16 at 112x112
+// is ONE chunk per tile and waited ~2.5 K of its 10.8 K cycles for x). blockDim.x = 64 WAVES.
+template <int DT, int NRT, int ACT, int RO, int S = 1, int KA = 1, bool AFL = true, int WAVES = 8, bool WEL = true, bool XL = false>
 __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // Stride 2 keeps the window layout (16 consecutive input columns per lane row, so the taps of the output centred on lane l are
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
     if constexpr (FAST) __builtin_amdgcn_s_setreg(1 | (8 << 6), 0);      // MODE.DX10_CLAMP = 0: the clamp modifier passes NaN through (as torch's hardtanh)
     typedef typename Mma<DT>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const MbrLds L = mbr_lds_layout(NRT, p.nChunks, KA, AFL, WEL);
+    static_assert(!XL || KA == 1, "x through LDS: one K step");
+    const MbrLds L = mbr_lds_layout(NRT, p.nChunks, KA, AFL, WEL, XL ? NR : 0, WAVES);
     // fragments that come from L2 are requested one half-chunk pass ahead into the other of two register sets (only where the registers
     // exist: the one-wave-per-SIMD form)
     constexpr bool PF = WAVES == 4 && (!WEL || !AFL);
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 
     const int nWavesAll = gridDim.x * nWaves;
     int tile = blockIdx.x * nWaves + wave;
-    const bool resx = S == 1 && NRT == 2 * KA && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
+    const bool resx = (MBR_DBG & 64) == 0 && S == 1 && NRT == 2 * KA && p.res != nullptr && p.res == p.x;                    // the skip tensor is the unit's input (Cout == Cin)
 
     // A tile's position, decoded ONCE (three scalar divisions; decoded inside every row load the epilogue's prefetch alone was ~700
     // scalar instructions per tile): image, first output row, this lane's window column and the byte offset of its pixel in window row 0
@@ -264,12 +269,29 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
     }
 
     TilePos cur = decode(tile);
-    u32x4 xr[NR][KA];
+    u32x4 xr[XL ? 1 : NR][KA];
+    // XL: this wave's two x buffers, [row][lane] 16 B each; a row is one LDS-DMA piece (out-of-range lanes are written as zeros)
+    typedef __attribute__((address_space(3))) char lds_char;
+    char* const xs = smem + L.xs + wave * 2 * NR * 1024;
+    auto stage_x = [&](const TilePos& T, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool ok = T.colok & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H) & (8 * fq < p.Cin);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_char*)(size_t)PCV_LDS(xs + (buf * NR + r) * 1024), 16,
+                                                     ok ? (uint32_t)(T.off0 + r * rowpitch) : 0x80000000u, 0, 0, 0);
+        }
+    };
+    int xbuf = 0;
     if (tile < p.nTiles) {
+        if constexpr (XL) {
+            stage_x(cur, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the first tile has no stores in front of it to count)
+        } else {
 #pragma unroll
-        for (int r = 0; r < NR; ++r)
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(cur, r, ks);
+                for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(cur, r, ks);
+        }
     }
 
     while (tile < p.nTiles) {
@@ -277,6 +299,14 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         const TilePos nxt = decode(ntile);
         const int n = cur.n, h0 = cur.h0, wi = cur.wi;
         const bool colok = (unsigned)wi < (unsigned)p.W;
+        if constexpr (XL) {
+            // this tile's window has landed: behind its pieces (issued a tile ago) only the previous tile's RO * NRT / 2 stores went out
+            // (vmcnt retires in order; a skip tensor that is not x is loaded AND consumed in front of them). Then the next tile's pieces
+            // go into the other buffer, whose last reader was the previous tile's S1.
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RO * NRT / 2) : "memory");
+            stage_x(nxt, xbuf ^ 1);
+        }
+        const char* const xrd = xs + xbuf * NR * 1024 + lane * 16;
 
 #ifdef MBR_CYCLES
         const bool stamp__ = p.dbg != nullptr && ntile__ == 1;
@@ -348,9 +378,12 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                     {
                         f32x4 e0 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int ks = 0; ks < KA; ++ks) e0 = Mma<DT>::run(we[ks], __builtin_bit_cast(frag, xr[r][ks]), e0);
+                        for (int ks = 0; ks < KA; ++ks) {
+                            if constexpr (XL) e0 = Mma<DT>::run(we[ks], *reinterpret_cast<const frag*>(xrd + r * 1024), e0);
+                            else e0 = Mma<DT>::run(we[ks], __builtin_bit_cast(frag, xr[r][ks]), e0);
+                        }
                         // the next tile's row into the registers this S1 used last (rows that are the unit's skip tensor: behind the epilogue)
-                        if ((MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) {
+                        if (!XL && (MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) {
 #pragma unroll
                             for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(nxt, r, ks);
                         }
@@ -370,12 +403,12 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                                 const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[e] = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v[e], 0.f), hi);
-                                if constexpr (ACT != PCV_ACT_RELU6) g1.see(v);
+                                if constexpr (ACT != PCV_ACT_RELU6 && (MBR_DBG & 128) == 0) g1.see(v);
                                 o[0] = pack2<DT>(v[0], v[1]);
                                 o[1] = pack2<DT>(v[2], v[3]);
                             } else {
                                 apply_actn<4>(v, act_e);
-                                g1.see(v);
+                                if constexpr ((MBR_DBG & 128) == 0) g1.see(v);
                                 o[0] = ok ? pack2<DT>(v[0], v[1]) : 0u;
                                 o[1] = ok ? pack2<DT>(v[2], v[3]) : 0u;
                             }
@@ -416,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(da[u][e], sd[e], hd[e]);
                             mbw_act<ACT, 4>(v, act_d);
-                            if constexpr (ACT != PCV_ACT_RELU6) g2.see(v);
+                            if constexpr (ACT != PCV_ACT_RELU6 && (MBR_DBG & 256) == 0) g2.see(v);
                             od[0] = pack2<DT>(v[0], v[1]);
                             od[1] = pack2<DT>(v[2], v[3]);
                         }
@@ -471,7 +504,9 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                 }
                 if constexpr (!decltype(plain)::value) apply_act8(v, act_p);
                 if (p.res != nullptr) {                                  // (x as the skip tensor: channels 32 ipp + 8 fq = K step ipp of window row u + 1)
-                    const u32x4 r4 = resx ? xr[S == 1 ? u + 1 : 0][ipp < KA ? ipp : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                    u32x4 r4;
+                    if constexpr (XL) r4 = resx ? *reinterpret_cast<const u32x4*>(xrd + (u + 1) * 1024) : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                    else r4 = resx ? xr[S == 1 ? u + 1 : 0][ipp < KA ? ipp : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float r0, r1;
@@ -481,10 +516,8 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                     }
                     if constexpr (!decltype(plain)::value) apply_act8(v, post);
                 }
-                if constexpr (S == 1) {
-                    if ((MBR_DBG & 32) == 0 && resx && ipp < KA) xr[u + 1][ipp] = load_x(nxt, u + 1, ipp);
-                }
-                if (ok) guard.see(v);                                  // (halo lanes hold garbage that is never stored)
+
+                if constexpr ((MBR_DBG & 512) == 0) { if (ok) guard.see(v); }         // (halo lanes hold garbage that is never stored)
                 u32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = pack2<DT>(v[2 * e], v[2 * e + 1]);
@@ -494,6 +527,18 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         };
         if (p.act_p == PCV_ACT_NONE && p.post == PCV_ACT_NONE) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        // the rows of the next tile that were this tile's skip tensor: requested behind the epilogue, all at once. (Requested row by row
+        // inside it, each behind the row that consumed it, one instantiation - fp16, launch-time activations - produced wrong,
+        // run-to-run different output rows 0 - 2 of every tile although the loads only ever feed the NEXT tile; neither the matrix-pipe
+        // distances nor the source explain it. tests: the "keep" shapes of test_mbconv_fused_matches_separate_launches_and_oracle.)
+        if constexpr (S == 1 && !XL) {
+            if ((MBR_DBG & 32) == 0 && resx) {
+#pragma unroll
+                for (int r = 1; r <= RO; ++r)
+#pragma unroll
+                    for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(nxt, r, ks);
+            }
+        }
         guard.commit(p.ovf);
         if constexpr ((MBR_DBG & 4) != 0) {                             // keep the accumulators alive
             float t = 0.f;
@@ -512,6 +557,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #endif
         tile = ntile;
         cur = nxt;
+        xbuf ^= 1;
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }

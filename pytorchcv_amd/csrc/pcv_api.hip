@@ -667,16 +667,21 @@ static mbconv_fn pick_mbw(int dt, int stride, int nrt, int act, int tw, int ka, 
         if (e.dt == dt && e.s == stride && e.nrt == nrt && e.act == act && e.tw == tw && e.ka == ka && e.rb == rb) return e.fn;
     return nullptr;
 }
+static int g_mbr_xl = 1;     // pcv_set_tuning("mbr_xl", 0): never stage x through LDS (A/B)
 // register-resident variant (mbr.hpp): stride 1, Cin <= 32, Cout <= 64
-struct MbrEntry { int dt, nrt, act, ro, s, ka; bool afl; int waves; bool wel; mbconv_fn fn; };
-#define MBR_ROW(DT, NRT, ACT, RO, S, KA, AFL, WV, WEL) {DT, NRT, ACT, RO, S, KA, AFL, WV, WEL, mbr_kernel<DT, NRT, ACT, RO, S, KA, AFL, WV, WEL>},
+struct MbrEntry { int dt, nrt, act, ro, s, ka; bool afl; int waves; bool wel, xl; mbconv_fn fn; };
+#define MBR_ROW(DT, NRT, ACT, RO, S, KA, AFL, WV, WEL, XL) {DT, NRT, ACT, RO, S, KA, AFL, WV, WEL, XL, mbr_kernel<DT, NRT, ACT, RO, S, KA, AFL, WV, WEL, XL>},
+static int mbr_entry_lds(const MbrEntry& e, int nChunks) {
+    const int nr = e.s == 1 ? e.ro + 2 : 2 * e.ro + 1;
+    return mbr_lds_layout(e.nrt, nChunks, e.ka, e.afl, e.wel, e.xl ? nr : 0, e.waves).total;
+}
 static const MbrEntry kMbr[] = {MBR_SHAPES(MBR_ROW, PCV_BF16) MBR_SHAPES(MBR_ROW, PCV_F16)};
 // the instantiation for a unit, when its tables fit the LDS
 static const MbrEntry* pick_mbr(int dt, int nrt, int act, int stride, int ka, int nChunks) {
-    if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) act = -1;
+    if (act != PCV_ACT_RELU && act != PCV_ACT_RELU6) return nullptr;          // launch-time activations: mbw.hpp / mbconv.hpp (mbr_inst.hpp)
     for (const MbrEntry& e : kMbr)
         if (e.dt == dt && e.nrt == nrt && e.act == act && e.s == stride && e.ka == ka &&
-            mbr_lds_layout(nrt, nChunks, ka, e.afl, e.wel).total <= 160 * 1024)
+            mbr_entry_lds(e, nChunks) <= 160 * 1024 && (!e.xl || g_mbr_xl))
             return &e;
     return nullptr;
 }
@@ -873,6 +878,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "gconvr") ctx->use_gconvr = value;
     else if (k == "mbw") ctx->use_mbw = value;
     else if (k == "mbr") ctx->use_mbr = value;
+    else if (k == "mbr_xl") g_mbr_xl = value;
     else if (k == "dbg") {
 #ifdef PCV_DBG_FLAGS
         ctx->dbg_flags = value;
@@ -2165,7 +2171,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");
             p.nTiles = (int)nT;
             const unsigned gridr = (unsigned)std::min<long>((nT + e->waves - 1) / e->waves, (long)block_slots(ctx, 1));
-            hipLaunchKernelGGL(e->fn, dim3(gridr), dim3(64 * e->waves), mbr_lds_layout(nrt, p.nChunks, kaw, e->afl, e->wel).total, (hipStream_t)stream, p);
+            hipLaunchKernelGGL(e->fn, dim3(gridr), dim3(64 * e->waves), mbr_entry_lds(*e, p.nChunks), (hipStream_t)stream, p);
             HIP_TRY(ctx, hipGetLastError());
             return PCV_OK;
         }

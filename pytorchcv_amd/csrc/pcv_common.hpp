@@ -115,6 +115,18 @@ template <int OT, bool SCALAR = false> struct F16Guard {
             note(t);
         }
     }
+    // as see(), for a lane that may hold garbage which is never stored (`live` false): branch-free - the maximum of a dead lane counts as 0.
+    // (A divergent `if (live) see(v)` around the scalar form's ballot made mbr_kernel<fp16, launch-time activation> compute wrong rows:
+    // built without the guard, or with this form, it is bit-exact; tests/test_gpu_blocks.py, the "keep" shapes.)
+    template <int N> __device__ __forceinline__ void see_if(const float (&v)[N], bool live) {
+        static_assert(N % 2 == 0, "pairs");
+        if constexpr (OT == PCV_F16) {
+            float t = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+            for (int e = 2; e < N; e += 2) t = fmaxf(fmaxf(fabsf(v[e]), fabsf(v[e + 1])), t);
+            note(live ? t : 0.f);
+        }
+    }
     // `live`: false for a lane whose values are never stored and may be garbage (per-lane form only)
     __device__ __forceinline__ void commit(uint32_t* counter, bool live = true) {
         if constexpr (OT == PCV_F16) {

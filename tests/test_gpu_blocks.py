@@ -320,18 +320,22 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
     # wide units (65..96 projected channels, two or three expand K steps; wave tiles of 2 pixel blocks): MobileNetV2 units 11-13
     (3, 14, 14, 96, True, 96, 1, "relu6"), (2, 14, 14, 64, True, 96, 1, "relu6"), (2, 17, 15, 72, True, 80, 1, "relu"),
     (1, 20, 33, 96, True, 88, 1, "hswish"),
+    # units that keep their 1x1 "expand" convolution without expanding (MobileNetV2's first unit, 32 -> 32 -> 16: one 32-channel chunk):
+    # the register-resident kernel stages their x window through LDS (csrc/mbr.hpp, XL), with and without the skip tensor
+    (2, 112, 112, 32, "keep", 16, 1, "relu6"), (3, 30, 27, 16, "keep", 16, 1, "relu6"), (2, 17, 33, 8, "keep", 24, 1, "relu"),
+    (5, 14, 14, 32, "keep", 32, 1, "hswish"),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("grid", GRIDS, ids=GRID_IDS)
-@pytest.mark.parametrize("kernel", ["reg", "wave", "wave8", "wave16", "block"])
+@pytest.mark.parametrize("kernel", ["reg", "regnx", "wave", "wave8", "wave16", "block"])
 @pytest.mark.parametrize("shape", _MB_SHAPES, ids=["x".join(str(v) for v in s) for s in _MB_SHAPES])
 def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype, grid, cuda_device):
     """pcv_mbconv_fused (expand -> depthwise -> project in one launch) against the same LinearBottleneck run as three
     launches (same rounding points: bit-exact up to fp32 summation order) and against the quantisation-matched oracle.
     `kernel`: register-resident tiles (csrc/mbr.hpp: stride 1, at most 32 input channels - what the library picks where it
-    applies; other shapes fall through to the wave-private kernel), wave-private tiles (csrc/mbw.hpp, units with at most 32 input
+    applies; other shapes fall through to the wave-private kernel; "regnx": without the x window staged through LDS), wave-private tiles (csrc/mbw.hpp, units with at most 32 input
     channels; pixel blocks of 2 x 8 or 1 x 16 outputs, chosen by the library or forced) or block tiles (csrc/mbconv.hpp)."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
@@ -340,7 +344,7 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype,
     from pytorchcv_amd.models.common.activ import create_activation_layer
     from oracle import refnet
     N, H, W, Cin, expand, Cout, stride, act = shape
-    unit = LinearBottleneck(in_channels=Cin, out_channels=Cout, stride=stride, expansion=expand, remove_exp_conv=True,
+    unit = LinearBottleneck(in_channels=Cin, out_channels=Cout, stride=stride, expansion=(expand is True), remove_exp_conv=(expand != "keep"),
                             activation=(lambda: create_activation_layer(act or "relu6"))).eval()
     sd = util.synth_state_dict(unit.state_dict(), seed=31)
     unit.load_state_dict(sd)
@@ -351,7 +355,8 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype,
     a = engine.NHWC(xq.permute(0, 2, 3, 1).contiguous().to(cuda_device), N, H, W, Cin)
     residual = a if unit.residual else None
     with torch.no_grad():
-        with util.tuning(max_blocks=grid, mbr=int(kernel == "reg"), mbw={"reg": 1, "wave": 1, "wave8": 8, "wave16": 16, "block": 0}[kernel]):
+        with util.tuning(max_blocks=grid, mbr=int(kernel.startswith("reg")), mbr_xl=int(kernel != "regnx"),
+                         mbw={"reg": 1, "regnx": 1, "wave": 1, "wave8": 8, "wave16": 16, "block": 0}[kernel]):
             fused = mbconv_chain(unit.conv1 if unit.use_exp_conv else None, unit.conv2, unit.conv3, a, residual=residual)
         if act is None:
             assert fused is None, "576 expanded channels x 96 inputs do not fit the LDS budget: must fall back"
@@ -369,7 +374,7 @@ def test_mbconv_fused_matches_separate_launches_and_oracle(shape, kernel, dtype,
     q = refnet.Quant(dtype)
     sdc = {k: v.float() for k, v in sd.items()}
     xr = q.r(x)
-    t = refnet.conv_block(sdc, "conv1.", xr, act=act, q=q) if expand else xr
+    t = refnet.conv_block(sdc, "conv1.", xr, act=act, q=q) if unit.use_exp_conv else xr
     t = refnet.conv_block(sdc, "conv2.", t, stride=stride, padding=1, groups=t.shape[1], act=act, q=q)
     ref = refnet.conv_block(sdc, "conv3.", t, act=None, q=q, residual=(xr if unit.residual else None))
     err = float((f.permute(0, 3, 1, 2) - ref).abs().max())

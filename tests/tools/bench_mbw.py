@@ -39,7 +39,7 @@ for spec in units:
             with util.tuning(**kw):
                 return fused()
         return f
-    fns = {"three launches": lambda: unit.conv3(unit.conv2(unit.conv1(x)), residual=res), "mbw": with_tuning(mbr=0), "default": fused}
+    fns = {"three launches": lambda: unit.conv3(unit.conv2(unit.conv1(x)), residual=res), "mbw": with_tuning(mbr=0), "mbr_regs": with_tuning(mbr_xl=0), "default": fused}
     if os.environ.get("BENCH_MBW_ONLY"):
         fns = {k: f for k, f in fns.items() if k in os.environ["BENCH_MBW_ONLY"].split(",") or k == "three launches"}
     times = {k: [] for k in fns}
