@@ -127,7 +127,10 @@ int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);
 /* w: fp32 OIHW [Cout, Cin/groups, kh, kw] exactly as `conv.weight` in the reference state_dict (conv.py:250-258)
  * -> packed: K-major, MFMA-row-ordered blob in d->dtype (layout in DESIGN.md). N/H/W of d are ignored. */
 int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream);
-/* Depthwise (groups == Cin == Cout, conv.py:437-473): w fp32 [C,1,kh,kw] -> packed [kh*kw][C] in dtype. */
+/* Depthwise (groups == Cin == Cout, conv.py:437-473): w fp32 [C,1,kh,kw] -> packed [kh*kw][C] in dtype. For 16-bit 3x3 filters the
+ * blob continues (from the next 16-byte boundary) with the same taps as the compressed diagonal fragments of the sparse matrix
+ * instruction, 6 KB per 32 channels - what pcv_mbconv_fused's register-resident kernel reads (csrc/mbr.hpp); always size the buffer
+ * with pcv_dwconv_packed_bytes. The depthwise kernels themselves read only the first part. */
 int pcv_dwconv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);
 int pcv_dwconv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream);
 /* Eval-mode BatchNorm2d (common/norm.py:34-50) folded to fp32 scale/shift; any of gamma..var NULL means "no BN"
