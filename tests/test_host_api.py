@@ -156,7 +156,15 @@ def test_packed_size_planning_is_pure_host_logic():
     # depthwise goes through its own entry point
     d = _desc(Cin=144, Cout=144, groups=144, x_cpitch=144)
     assert L.pcv_dwconv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
-    assert n.value == 9 * 144 * 2
+    # the taps [9][144] (rounded up to 16 bytes), then - 16-bit 3x3 - the compressed diagonal fragments of the sparse matrix instruction for
+    # the fused inverted-residual kernel: 5 chunks of 32 channels x 6 fragments x 1 KB (csrc/aux_kernels.hpp pack_dw_sparse_kernel)
+    assert n.value == 9 * 144 * 2 + 5 * 6 * 1024
+    d = _desc(Cin=144, Cout=144, groups=144, x_cpitch=144, dtype=0, out_dtype=0)       # fp32: the taps only
+    assert L.pcv_dwconv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    assert n.value == 9 * 144 * 4
+    d = _desc(Cin=40, Cout=40, groups=40, x_cpitch=40, kh=5, kw=5, pad_t=2, pad_b=2, pad_l=2, pad_r=2)       # 5x5: the taps only (25 x 40 x 2 = 2000 bytes)
+    assert L.pcv_dwconv_packed_bytes(ctypes.byref(d), ctypes.byref(n)) == 0
+    assert n.value == 2000
 
 
 @pytest.mark.parametrize("bad", [dict(groups=3), dict(kh=16), dict(dtype=7), dict(out_dtype=2), dict(x_cpitch=60),

@@ -104,7 +104,8 @@ for dt in (0, 1, 2):
     for k in (3, 5):
         for s in (1, 2):
             d = desc(dtype=dt, out_dtype=dt, Cin=96, Cout=96, groups=96, kh=k, kw=k, stride_h=s, stride_w=s, pad_t=k // 2, pad_l=k // 2, pad_b=k // 2, pad_r=k // 2)
-            assert size(d, dw=True) == 0 and n.value == k * k * 96 * (4 if dt == 0 else 2)
+            taps = (k * k * 96 * (4 if dt == 0 else 2) + 15) // 16 * 16
+            assert size(d, dw=True) == 0 and n.value == taps + (3 * 6 * 1024 if (k == 3 and dt != 0) else 0)      # 16-bit 3x3: + the sparse-MFMA fragments
 # refused, never read out of bounds or overflowed: bad counts, sizes at the edge of int32, a stale struct_size, unknown dtypes
 bad = [dict(Cin=0), dict(Cout=-8), dict(kh=0), dict(kh=16, kw=16), dict(stride_h=0), dict(dil_w=-1), dict(groups=0), dict(groups=3), dict(dtype=7), dict(out_dtype=2, dtype=1),
        dict(x_cpitch=32), dict(Cin=BIG, Cout=BIG), dict(Cin=BIG - 6, Cout=8), dict(Cin=8, Cout=BIG - 6), dict(N=BIG, H=BIG, W=BIG), dict(kh=15, kw=15, Cin=1 << 24, Cout=1 << 20),
