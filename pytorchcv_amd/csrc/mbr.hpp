@@ -268,6 +268,9 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         if constexpr (!AFL) fetch_af(0, afG[0]);
     }
 
+    // the B tuples of the sparse MFMAs, {left, centre, right, 0} x 2 dwords: slots 0 .. 5 are rewritten per window row, the padding slots
+    // 6, 7 stay zero (as fresh values per row they cost two v_mov per tuple plus the compiler's tuple copies: 62 of a chunk's 320 VALU)
+    u32x8 RT[2] = {(u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, (u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     TilePos cur = decode(tile);
     u32x4 xr[XL ? 1 : NR][KA];
     // XL: this wave's two x buffers, [row][lane] 16 B each; a row is one LDS-DMA piece (out-of-range lanes are written as zeros)
@@ -374,7 +377,8 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     // ---- S1: window row r of the E half-chunk ----------------------------------------------------------------------
-                    u32x8 b8;
+                    u32x8 fresh = (u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    u32x8& b8 = KA == 1 ? RT[r & 1] : fresh;             // (two persistent tuples, alternating; with two expand K steps their 16 registers spill)
                     {
                         f32x4 e0 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -417,8 +421,13 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                             o[0] = __float_as_uint(e0[0]) ^ __float_as_uint(e0[1]);
                             o[1] = __float_as_uint(e0[2]) ^ __float_as_uint(e0[3]);
                         }
-                        if constexpr ((MBR_DBG & 2) != 0) b8 = (u32x8){o[0], o[1], o[0], o[1], o[0], o[1], 0u, 0u};
-                        else b8 = (u32x8){mbr_dpp<0x111>(o[0]), mbr_dpp<0x111>(o[1]), o[0], o[1], mbr_dpp<0x101>(o[0]), mbr_dpp<0x101>(o[1]), 0u, 0u};   // row_shr:1 = the pixel to the left, row_shl:1 = to the right
+                        if constexpr ((MBR_DBG & 2) != 0) {
+                            b8[0] = o[0]; b8[1] = o[1]; b8[2] = o[0]; b8[3] = o[1]; b8[4] = o[0]; b8[5] = o[1];
+                        } else {
+                            b8[0] = mbr_dpp<0x111>(o[0]); b8[1] = mbr_dpp<0x111>(o[1]);          // row_shr:1 = the pixel to the left
+                            b8[2] = o[0]; b8[3] = o[1];
+                            b8[4] = mbr_dpp<0x101>(o[0]); b8[5] = mbr_dpp<0x101>(o[1]);          // row_shl:1 = the pixel to the right
+                        }
                     }
                     // ---- S2: filter row 2 of output row r - 2 (complete behind it), 1 of r - 1, 0 of r ------------------------------------
                     const typename MmaSp<DT>::bfrag R = __builtin_bit_cast(typename MmaSp<DT>::bfrag, b8);
