@@ -118,6 +118,18 @@ __global__ __launch_bounds__(256) void pack_dw_kernel(const float* __restrict__ 
     store_elem<DT>(out, (size_t)i, w[(size_t)c * khkw + k]);
 }
 
+// dense 3x3 with 256 input channels, 16-bit (d3i_conv.hpp): the packed rows [row][Kpad] -> MFMA A fragments in the order a wave loads them,
+// [64-row group][K-half kh = 0 .. Kpad / 32 - 1][16-row block nb][lane] 16 B: lane (fr, fq) holds row 64 grp + 16 nb + fr, K elements
+// 32 kh + 8 fq .. + 7 - one coalesced 1 KB load per fragment.
+__global__ __launch_bounds__(256) void pack_d3i_kernel(const u32x4* __restrict__ blob, u32x4* __restrict__ table, int Kpad, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, nb = (idx >> 6) & 3, nkh = Kpad / 32;
+    const int kh = (idx >> 8) % nkh, grp = (idx >> 8) / nkh;
+    const int row = 64 * grp + 16 * nb + (lane & 15);
+    table[idx] = blob[((size_t)row * Kpad + 32 * kh + 8 * (lane >> 4)) / 8];
+}
+
 // depthwise 3x3, 16-bit: the packed taps [9][C] -> the compressed diagonal A fragments of the SPARSE matrix instruction
 // (v_smfmac_f32_16x16x64, csrc/mbr.hpp MmaSp: the operand layout is documented and probed there), [chunk of 32 channels][half g]
 // [filter row dy][lane] 16 B. Row i of a fragment is channel 32 c + 8 (i / 4) + 4 g + i % 4; B's lane quarter i / 4 supplies it at

@@ -14,6 +14,7 @@
 #include "d3w_inst.hpp"
 #include "d3c_conv.hpp"
 #include "d3k_conv.hpp"
+#include "d3i_conv.hpp"
 #include "p1r_conv.hpp"
 #include "stem_conv.hpp"
 #include "pair1x1.hpp"
@@ -51,6 +52,8 @@ extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
 extern template __global__ void d3k_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3k_kernel<PCV_F16>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_BF16>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_F16>(const D3Params);
 #define P1R_DECLARE(CW, CIN)                                                       \
     extern template __global__ void p1r_kernel<PCV_BF16, CW, CIN>(const D3Params); \
     extern template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
@@ -76,6 +79,7 @@ struct pcv_ctx {
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
     int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3k = -1;           // 128-input-channel dense 3x3 kernel on 28-wide maps (d3k_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
+    int use_d3i = -1;           // 256-input-channel dense 3x3 kernel with the image in LDS (d3i_conv.hpp; maps up to 14 x 14): -1 = where it applies and half-fills the chip, 0 = never, 1 = wherever it applies
     int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
@@ -143,6 +147,8 @@ struct ConvPlan {
     size_t ktab_bytes = 0, w_bytes = 0, total_bytes = 0;
     int gconv_kt = 5;         // K-steps per slab of that blob: 5 (tap pairs x 16 channels; 4/8/16 channels per group) or 9 (taps x 32 channels)
     bool gconv = false;       // grouped 3x3/p1, stride 1 or 2, 4/8/16/32 channels per group: a second blob for gconv3x3(r).hpp follows the generic
+    bool d3i = false;         // dense 3x3/s1/p1, 16 bit, 256 input channels, Cout % 64 == 0: a fragment-ordered copy of the weights for d3i_conv.hpp
+    size_t d3i_off = 0;       // follows the generic blob (whether a launch takes that kernel depends on the map size)
     size_t gconv_off = 0;     // one (the choice between the two kernels depends on the map width, known only at launch)
     std::vector<uint32_t> ktab;   // built only when tables == true
     std::vector<uint32_t> ksrc;
@@ -240,6 +246,12 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
         P.gconv_kt = P.Cg_in == 32 ? 9 : 5;
         P.gconv_off = (P.total_bytes + 15) / 16 * 16;
         P.total_bytes = P.gconv_off + (size_t)(d.Cin / 16) * P.gconv_kt * 16 * 32 * P.ES;
+    }
+    P.d3i = P.conv3 && P.ES == 2 && d.Cin == D3ICfg::CIN && d.Cout % D3ICfg::CW == 0 && d.out_dtype == d.dtype &&
+            P.wrows >= d.Cout && P.Kpad == 9 * D3ICfg::CIN;
+    if (P.d3i) {
+        P.d3i_off = (P.total_bytes + 15) / 16 * 16;
+        P.total_bytes = P.d3i_off + (size_t)(d.Cout / D3ICfg::CW) * D3ICfg::WBYTES;
     }
     if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
 
@@ -464,6 +476,7 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
+static const void* kD3I[2] = {reinterpret_cast<const void*>(d3i_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16>)};
 static const void* kD3K[2] = {reinterpret_cast<const void*>(d3k_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3k_kernel<PCV_F16>)};
 // p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels), [2] 256 input channels with
 // 32 channels per wave (a skip tensor, or fewer than 384 output channels)
@@ -476,6 +489,7 @@ static int enable_d3x3(pcv_ctx* ctx) {
         for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3K[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3KCfg::LDS));
+    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfg::LDS));
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
@@ -871,6 +885,7 @@ int pcv_set_tuning(pcv_ctx* ctx, const char* key, int value) {
     else if (k == "d3w") ctx->use_d3w = value;
     else if (k == "d3c") ctx->use_d3c = value;
     else if (k == "d3k") ctx->use_d3k = value;
+    else if (k == "d3i") ctx->use_d3i = value;
     else if (k == "p1r") ctx->use_p1r = value;
     else if (k == "head") ctx->use_head = value;
     else if (k == "stem32") ctx->use_stem32 = value;
@@ -1102,6 +1117,11 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
         } else if (bf) pack_gconv_kernel<PCV_BF16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
         else pack_gconv_kernel<PCV_F16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
     }
+    if (P.d3i) {
+        const int total = d->Cout / D3ICfg::CW * (D3ICfg::WBYTES / 16);
+        pack_d3i_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(reinterpret_cast<const u32x4*>(pp.out),
+                                                                        reinterpret_cast<u32x4*>(static_cast<char*>(packed) + P.d3i_off), P.Kpad, total);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(ksrc_dev);
@@ -1181,6 +1201,7 @@ enum ConvKernel {
     CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
+    CK_D3I,         // d3i_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 256 input channels on maps up to 14 x 14 (image in LDS, weights straight to registers)
     CK_D3K,         // d3k_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 128 input channels on 28-wide maps (weights in registers / AGPRs)
     CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
@@ -1273,6 +1294,13 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
             d->W == D3KCfg::W && G.cpitch == d->Cin && G.wpitch == d->W) {
             const long long tiles = (long long)((d->Cout + D3KCfg::BM - 1) / D3KCfg::BM) * d->N * ((d->H + D3KCfg::ROWS - 1) / D3KCfg::ROWS);
             if (ctx->use_d3k > 0 || tiles >= 2ll * block_slots(ctx, 1)) { R.kernel = CK_D3K; return R; }
+        }
+        // 256 input channels on a map of up to 14 x 14 (ResNet stage 3): one image x 256 channels per block; automatic choice for (almost)
+        // full 13-block images from half a round of the CUs up
+        if (P.d3i && ctx->use_d3i != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3i > 0) && (ctx->use_d3w <= 0 || ctx->use_d3i > 0) &&
+            d->H <= D3ICfg::MAXW && d->W <= D3ICfg::MAXW && G.cpitch == d->Cin && G.wpitch == d->W) {
+            const long long tiles = (long long)((d->Cout + D3ICfg::BM - 1) / D3ICfg::BM) * d->N;
+            if (ctx->use_d3i > 0 || (d->H * d->W > 16 * (D3ICfg::NBLK - 1) - 16 && 2 * tiles >= (long long)ctx->num_cu)) { R.kernel = CK_D3I; return R; }
         }
         if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
             R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
@@ -1478,6 +1506,36 @@ static int launch_d3q(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     return PCV_OK;
 }
 
+// d3i_kernel: one block per (image, 256-channel tile); the parameter block of the other dense 3x3 kernels
+static int launch_d3i(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
+    const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
+    const unsigned long long ybytes = ((G.M64 - 1) * (unsigned long long)ypitch + d->Cout) * 2ull;
+    if (ypitch < d->Cout || (ypitch * 2) % 16 != 0)
+        return fail(ctx, PCV_ERR_INVALID, "pcv_conv2d_fused: y_cpitch must be >= Cout and a multiple of 16 bytes");
+    if (ybytes >= 0x80000000ull)
+        return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: output exceeds the 2 GiB window of one launch; split the batch");
+    D3Params q;
+    std::memset(&q, 0, sizeof(q));
+    q.x = A.x; q.w = static_cast<const char*>(A.packed) + P.d3i_off; q.res = d->has_residual ? A.residual : nullptr; q.y = A.y;
+    q.scale = A.scale; q.shift = A.shift; q.ovf = ctx->ovf;
+    q.x_bytes = (uint32_t)G.xbytes; q.w_bytes = (uint32_t)(P.total_bytes - P.d3i_off); q.y_bytes = (uint32_t)ybytes;
+    q.res_bytes = (uint32_t)(G.M64 * (unsigned long long)d->Cout * 2ull);
+    q.M = (int)G.M64; q.Cout = d->Cout; q.Ypitch = ypitch; q.Cin = d->Cin; q.Kpad = P.Kpad;
+    q.H = d->H; q.W = d->W; q.HW = d->H * d->W; q.Hin = d->H; q.Win = d->W; q.stride = 1;
+    q.div_w = make_fastdiv((uint32_t)d->W);
+    q.div_hw = make_fastdiv((uint32_t)q.HW);
+    q.nk = P.nk; q.slices = d->Cin / 64;
+    q.act = d->act; q.post_act = d->post_act;
+    q.nChTiles = (d->Cout + D3ICfg::BM - 1) / D3ICfg::BM;
+    const long long nT = (long long)d->N * q.nChTiles;
+    if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
+    q.nTiles = (int)nT;
+    q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);       // (diagnostic builds: -DD3I_CYCLES)
+    void* args[] = {&q};
+    HIP_TRY(ctx, hipLaunchKernel(kD3I[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nT), dim3(D3ICfg::THREADS), args, (size_t)D3ICfg::LDS, A.stream));
+    return PCV_OK;
+}
+
 // dense layer on a 1x1 map, fp32 (classifier): many small blocks instead of a handful of 128x128 tiles
 static int launch_head(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, const ConvGeom& G, const ConvArgs& A) {
     const int ypitch = d->y_cpitch > 0 ? d->y_cpitch : d->Cout;
@@ -1614,6 +1672,7 @@ static int conv2d_impl(pcv_ctx* ctx, const pcv_conv_desc* d, const void* x, cons
         case CK_GCONV_FLAT: return launch_gconv_flat(ctx, d, P, G, A);
         case CK_D3C: return launch_d3q(ctx, d, P, G, A, 0, false, false, true);
         case CK_D3K: return launch_d3q(ctx, d, P, G, A, 1, false, false, true);
+        case CK_D3I: return launch_d3i(ctx, d, P, G, A);
         case CK_D3W: return launch_d3q(ctx, d, P, G, A, R.shape, false, true);
         case CK_D3Q: return launch_d3q(ctx, d, P, G, A, R.shape, false);
         case CK_P1R: return launch_d3q(ctx, d, P, G, A, R.shape, true, false, false, true);

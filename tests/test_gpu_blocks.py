@@ -664,9 +664,50 @@ def test_conv3x3_c128_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
+_D3I_SHAPES = [  # (N, Cout, H, W, residual): 256 input channels on maps up to 14 x 14 (csrc/d3i_conv.hpp: the image in LDS, one block per image)
+    (3, 256, 14, 14, False), (2, 256, 14, 14, True), (2, 512, 14, 14, True), (3, 192, 13, 14, True), (2, 64, 14, 11, False), (5, 320, 7, 7, True),
+    (1, 256, 1, 1, False), (2, 128, 3, 14, True), (9, 256, 14, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _D3I_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D3I_SHAPES])
+def test_conv3x3_c256_kernel_equals_generic_and_oracle(shape, dtype, cuda_device):
+    """d3i_kernel (256 input channels, maps up to 14 x 14: ResNet stage 3, reference resnet.py:49,56,120-127): bit-identical to the generic
+    implicit GEMM (same K order, same MFMA chain per accumulator; its weights come from a fragment-ordered copy of the packed blob) on full
+    14 x 14 images, smaller and non-square maps (zero frame / unused pixel blocks), one / two / ragged channel tiles (64 .. 512 output
+    channels), with and without the residual epilogue; and within the 16-bit bound of the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv3x3_block
+    from oracle import refnet
+    N, Cout, H, W, use_res = shape
+    C = 256
+    blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=83)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=27)
+    res = util.synth_input(N, Cout, H, W, seed=28) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        with util.tuning(d3i=1):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        with util.tuning(d3x3=0):
+            yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        assert torch.equal(yh.t, yg.t), "d3i differs from the generic implicit GEMM in {} elements".format(int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), padding=1, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
 _RW_KERNELS = {  # kernel -> (ConvBlock factory name, input channels, H, W, tuning key that forces it, tuning that gives the generic kernel)
     "d3c": ("conv3x3_block", 64, 12, 56, "d3c", {"d3x3": 0}),
     "d3k": ("conv3x3_block", 128, 12, 28, "d3k", {"d3x3": 0}),
+    "d3i": ("conv3x3_block", 256, 14, 14, "d3i", {"d3x3": 0}),
     "p1r": ("conv1x1_block", 512, 14, 14, "p1r", {"d1x1": 0}),
     "p1r256": ("conv1x1_block", 256, 14, 14, "p1r", {"d1x1": 0}),
 }
