@@ -226,21 +226,25 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     const float clo = alo > plo ? alo : plo, chi = ahi < phi ? ahi : phi;
     const int mImg = n * HW;
     F16Guard<DT> guard;
+    // the skip tensor's 26 pieces of this lane, all requested up front (the fragment and weight registers are free now): one exposed HBM
+    // latency instead of two, under the first half's BN arithmetic
+    u32x4 rr[2][NB];
+    if (has_res) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int mb = 0; mb < NB; ++mb) {
+                const int pix = 16 * mb + fr, ch0 = chw + 32 * g;
+                const uint32_t roff = (ch0 < p.Cout && pix < HW) ? (uint32_t)(((mImg + pix) * p.Cout + ch0) * 2) : 0x80000000u;
+                rr[g][mb] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
+            }
+    }
     auto half = [&](auto HRc, auto Gc) __attribute__((always_inline)) {
         constexpr bool HR = decltype(HRc)::value;
         constexpr int g = decltype(Gc)::value;
         const int ch0 = chw + 32 * g;
         const bool chok = ch0 < p.Cout;
         const f32x4 es0 = es[g][0], es1 = es[g][1], eh0 = eh[g][0], eh1 = eh[g][1];
-        u32x4 rr[NB];
-        if constexpr (HR) {
-#pragma unroll
-            for (int mb = 0; mb < NB; ++mb) {
-                const int pix = 16 * mb + fr;
-                const uint32_t roff = (chok && pix < HW) ? (uint32_t)(((mImg + pix) * p.Cout + ch0) * 2) : 0x80000000u;
-                rr[mb] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
-            }
-        }
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) {
             u32x4 o;
@@ -255,7 +259,7 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
                     v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, alo), ahi);
                     v1 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v1, alo), ahi);
                     float lo, hi;
-                    unpack2<DT>(rr[mb][e], lo, hi);
+                    unpack2<DT>(rr[g][mb][e], lo, hi);
                     v0 += lo;
                     v1 += hi;
                     v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, plo), phi);

@@ -1296,11 +1296,12 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
             if (ctx->use_d3k > 0 || tiles >= 2ll * block_slots(ctx, 1)) { R.kernel = CK_D3K; return R; }
         }
         // 256 input channels on a map of up to 14 x 14 (ResNet stage 3): one image x 256 channels per block; automatic choice for (almost)
-        // full 13-block images from half a round of the CUs up
+        // full 13-block images from three quarters of a round of the CUs up (rocprofv3, batch 256 / 128: 47.6 / 39.9 us against d3w 59.0 /
+        // d3q 34.9 - a block takes ~40 us however few there are)
         if (P.d3i && ctx->use_d3i != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3i > 0) && (ctx->use_d3w <= 0 || ctx->use_d3i > 0) &&
             d->H <= D3ICfg::MAXW && d->W <= D3ICfg::MAXW && G.cpitch == d->Cin && G.wpitch == d->W) {
             const long long tiles = (long long)((d->Cout + D3ICfg::BM - 1) / D3ICfg::BM) * d->N;
-            if (ctx->use_d3i > 0 || (d->H * d->W > 16 * (D3ICfg::NBLK - 1) - 16 && 2 * tiles >= (long long)ctx->num_cu)) { R.kernel = CK_D3I; return R; }
+            if (ctx->use_d3i > 0 || (d->H * d->W > 16 * (D3ICfg::NBLK - 1) - 16 && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D3I; return R; }
         }
         if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
             R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
