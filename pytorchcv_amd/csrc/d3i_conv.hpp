@@ -23,29 +23,41 @@
 // allocated so that the fragment reads issued ahead of the last K-half (filter row "3") stay inside the allocation.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include "pcv_common.hpp"
 #include "igemm_conv.hpp"     // Mma<DT>
 #include "d3q_conv.hpp"       // D3Params, d3q_sync
 
-struct D3ICfg {
+// CIN = 512 (ResNet stage 4: 7 x 7 maps, three layers of ResNet-50, three to five of ResNet-18 / 34): the same kernel with TWO images per block,
+// stacked in one 17 x 9 grid that shares the zero row between them (153 slots of 1 040 bytes = 159 KB); 98 pixels = 7 pixel blocks per
+// wave (112 accumulator registers), 144 K-halves, eight 64-channel slices.
+template <int CIN_> struct D3ICfgT {
     static constexpr int THREADS = 256;
-    static constexpr int CIN = 256, SLICES = 4;
-    static constexpr int MAXW = 14;                          // map height and width up to 14
-    static constexpr int GW = 16;                            // slots per grid row (and image rows + frame)
-    static constexpr int NBLK = 13;                          // pixel blocks: 208 >= 14 * 14
+    static constexpr int CIN = CIN_, SLICES = CIN / 64;
+    static constexpr int NIMG = CIN == 256 ? 1 : 2;          // images per block
+    static constexpr int MAXW = CIN == 256 ? 14 : 7;         // map height and width up to MAXW
+    static constexpr int GW = MAXW + 2;                      // slots per grid row
+    static constexpr int IROWS = MAXW + 1;                   // grid rows from one image's first row to the next one's (a shared zero row)
+    static constexpr int GROWS = NIMG * IROWS + 1;           // grid rows: 16 / 17
+    static constexpr int NBLK = (NIMG * MAXW * MAXW + 15) / 16;      // pixel blocks per wave: 13 (208 >= 196) / 7 (112 >= 98)
     static constexpr int BM = 256, CW = 64;                  // output channels per block / per wave
-    static constexpr int PITCH = CIN * 2 + 16;               // 528 B per slot
-    static constexpr int ROWB = GW * PITCH;                  // 8 448 B per grid row
-    static constexpr int LDS = (GW + 1) * ROWB;              // 143 616 B: 16 grid rows + the row the look-ahead reads of the last K-half touch
-    static constexpr int KH = 9 * SLICES * 2;                // 72 K-halves
-    static constexpr int JR = KH / 3;                        // 24 per filter row
+    static constexpr int PITCH = CIN * 2 + 16;               // 528 / 1 040 B per slot
+    static constexpr int ROWB = GW * PITCH;                  // 8 448 / 9 360 B per grid row
+    static constexpr int NSLOT = GROWS * GW;                 // 256 / 153
+    // 256: one more grid row, which the look-ahead reads of the last K-half touch (143 616 B); 512: those reads are not issued (159 120 B)
+    static constexpr int LDS = NSLOT * PITCH + (CIN == 256 ? ROWB : 0);
+    static constexpr int KH = 9 * SLICES * 2;                // 72 / 144 K-halves
+    static constexpr int JR = KH / 3;                        // 24 / 48 per filter row
     static constexpr int PFW = 3, WRING = 4;                 // weights: K-halves of look-ahead, ring slots
-    static constexpr int WBYTES = KH * 4 * 1024;             // 294 912 B: the fragment-ordered weights of one wave (64 channels)
+    static constexpr int WBYTES = KH * 4 * 1024;             // the fragment-ordered weights of one wave (64 channels)
+    static constexpr int SPT = (NSLOT * 8 + THREADS - 1) / THREADS;  // staging pieces (16 B of a 64-channel slice) per thread: 8 / 5
     static_assert(JR % WRING == 0 && JR % 2 == 0, "ring slots are compile-time inside the filter-row loop");
-    // byte offset of K-half j = (slice, filter column, half) of a filter row behind a window's top-left slot (j >= 24: the next row's)
+    // byte offset of K-half j = (slice, filter column, half) of a filter row behind a window's top-left slot (j >= JR: the next row's)
     static constexpr int pimm(int j) { return (j >= JR ? ROWB : 0) + (((j % JR) % 6) >> 1) * PITCH + ((j % JR) / 6) * 128 + (j & 1) * 64; }
     static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(ROWB + pimm(JR - 1) < 65536, "fragment offsets are 16-bit immediates");
 };
+typedef D3ICfgT<256> D3ICfg;
 
 // Timing experiments (tests/tools/sh/d3i_variants.sh; results are WRONG with a bit set): 1 = no fragment reads in the K loop, 2 = no weight
 // loads in the K loop. -DD3I_CYCLES: shader-cycle stamps per wave into p.dbg (tests/tools/d3i_cycles.py).
@@ -54,9 +66,12 @@ struct D3ICfg {
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-template <int DT>
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <class F, int... I> __device__ __forceinline__ void d3i_unroll(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+
+template <int DT, int CIN>
 __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
-    typedef D3ICfg G;
+    typedef D3ICfgT<CIN> G;
     typedef typename Mma<DT>::frag frag;
     typedef const __attribute__((address_space(3))) frag* lds_fptr;
     typedef __attribute__((address_space(3))) u32x4* lds_wptr;
@@ -65,8 +80,9 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // output channels 64 wave .. of the tile
     const int fr = lane & 15, fq = lane >> 4;
     const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)PCV_LDS(smem));
-    const int chTile = (int)blockIdx.x % p.nChTiles, n = (int)blockIdx.x / p.nChTiles;
+    const int chTile = (int)blockIdx.x % p.nChTiles, n = (int)blockIdx.x / p.nChTiles * G::NIMG;      // first image of the block
     const int W = p.W, HW = p.HW;
+    const int NP = (n + G::NIMG <= p.M / HW ? G::NIMG : 1) * HW;      // pixels of the block (an odd batch: the last block has one image)
 #ifdef D3I_CYCLES
     uint64_t cyc__[6];
     cyc__[0] = __builtin_amdgcn_s_memtime();
@@ -74,8 +90,8 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
 #endif
 
     const uint32_t imgBytes = (uint32_t)(HW * G::CIN * 2);
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + (size_t)n * imgBytes, 0, imgBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) + (size_t)n * imgBytes, 0,
+                                                                           (uint32_t)(NP * G::CIN * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const bool has_res = p.res != nullptr;
@@ -99,35 +115,58 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     wload(2, std::integral_constant<int, 2>{});
     static_assert(G::PFW == 3, "the three loads above");
 
-    // ---- the image: 256 slots x 32 chunks of 16 B, eight per thread and 64-channel slice; a thread keeps its grid column gx = (tid >> 3) & 15
-    // and chunk, its grid row is 2 i + (tid >> 7). Frame slots and slots outside an H x W map smaller than 14 x 14 are out of range: zeros.
-    // Slice 0 is staged here; slices 1 .. 3 arrive under the MFMAs of filter row 0, whose K-halves 6 g .. 6 g + 5 read slice g. ----
-    // (grid rows above / below the map are out of range by themselves: h = -1 wraps below zero, h >= H lies behind the image's num_records;
-    // a thread in a frame column starts at 2^31 and stays out of range: one base register per thread, the same arithmetic for every piece)
-    const int sgx = (tid >> 3) & 15, sgy0 = tid >> 7, sc8 = tid & 7;
-    const uint32_t sbase = (unsigned)(sgx - 1) < (unsigned)W ? (uint32_t)((((sgy0 - 1) * W + sgx - 1) * G::CIN + sc8 * 8) * 2) : 0x80000000u;
-    const uint32_t srow2 = (uint32_t)(2 * W * G::CIN * 2);         // two map rows
-    const uint32_t slds = lds0 + (uint32_t)((sgy0 * G::GW + sgx) * G::PITCH + sc8 * 16);
-    u32x4 sb[8];
+    // ---- the image(s): NSLOT slots x 16-byte pieces, SPT per thread and 64-channel slice. Frame slots and slots outside an H x W map smaller
+    // than the grid are out of range: zeros. Slice 0 is staged here; the others arrive under the MFMAs of filter row 0, whose K-halves
+    // 6 g .. 6 g + 5 read slice g. ----
+    u32x4 sb[G::SPT];
+    uint32_t soff[CIN == 256 ? 1 : G::SPT];
+    uint32_t slds;
+    const int sc8 = tid & 7;
+    if constexpr (CIN == 256) {
+        // a thread keeps its grid column gx = (tid >> 3) & 15, its grid row is 2 i + (tid >> 7). Grid rows above / below the map are out of
+        // range by themselves (h = -1 wraps below zero, h >= H lies behind the image's num_records); a thread in a frame column starts at
+        // 2^31 and stays out of range: one base register per thread, the same arithmetic for every piece
+        const int sgx = (tid >> 3) & 15, sgy0 = tid >> 7;
+        soff[0] = (unsigned)(sgx - 1) < (unsigned)W ? (uint32_t)((((sgy0 - 1) * W + sgx - 1) * G::CIN + sc8 * 8) * 2) : 0x80000000u;
+        slds = lds0 + (uint32_t)((sgy0 * G::GW + sgx) * G::PITCH + sc8 * 16);
+    } else {
+        // piece i of a thread: slot 32 i + (tid >> 3) of the 17 x 9 grid (slots 153 .. 159 do not exist: nothing is written)
+#pragma unroll
+        for (int i = 0; i < G::SPT; ++i) {
+            const int slot = 32 * i + (tid >> 3), gy = slot / G::GW, gx = slot - gy * G::GW;
+            const int img = gy >= G::IROWS + 1 ? 1 : 0, h = gy - 1 - img * G::IROWS, w = gx - 1;
+            soff[i] = ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)W) ? (uint32_t)(((img * HW + h * W + w) * G::CIN + sc8 * 8) * 2) : 0x80000000u;
+        }
+        slds = lds0 + (uint32_t)((tid >> 3) * G::PITCH + sc8 * 16);
+    }
+    const uint32_t srow2 = (uint32_t)(2 * W * G::CIN * 2);         // (256: two map rows)
     auto sload = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sb[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, sbase + (uint32_t)i * srow2 + (uint32_t)(g * 128), 0, 0);
+        for (int i = 0; i < G::SPT; ++i)
+            sb[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (CIN == 256 ? soff[0] + (uint32_t)i * srow2 : soff[CIN == 256 ? 0 : i]) + (uint32_t)(g * 128), 0, 0);
     };
     auto swrite = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(2 * i * G::ROWB + g * 128))) = sb[i];
+        for (int i = 0; i < G::SPT; ++i) {
+            if constexpr (CIN == 256) {
+                *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(2 * i * G::ROWB + g * 128))) = sb[i];
+            } else {
+                if (32 * i + (tid >> 3) < G::NSLOT) *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(32 * i * G::PITCH + g * 128))) = sb[i];
+            }
+        }
     };
     sload(0);
     swrite(0);
 
-    // ---- fragment addresses: block mb's lane pixel p = 16 mb + fr at the window's top-left slot (filter row r, column q: + (16 r + q) slots);
-    // pixels behind the map read slot 0 (zeros; never stored) ----
+    // ---- fragment addresses: block mb's lane pixel p = 16 mb + fr (image p / HW, its pixel p % HW) at the window's top-left slot (filter row
+    // r, column q: + (GW r + q) slots); pixels behind the block's images read slot 0 (zeros; never stored) ----
     uint32_t ab[NB];
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
         const int pix = 16 * mb + fr;
-        const int py = (int)fastdiv((uint32_t)pix, p.div_w), px = pix - py * W;
-        ab[mb] = lds0 + (uint32_t)(pix < HW ? (py * G::GW + px) * G::PITCH : 0) + (uint32_t)(fq * 16);
+        const int img = (G::NIMG > 1 && pix >= HW) ? 1 : 0, loc = pix - img * HW;
+        const int py = (int)fastdiv((uint32_t)loc, p.div_w), px = loc - py * W;
+        ab[mb] = lds0 + (uint32_t)(pix < NP ? ((img * G::IROWS + py) * G::GW + px) * G::PITCH : 0) + (uint32_t)(fq * 16);
     }
 
     f32x4 acc[NB][4];
@@ -149,26 +188,20 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
         constexpr int j = decltype(Jc)::value, mb = decltype(MBc)::value;
         Pf[j & 1][mb] = *reinterpret_cast<lds_fptr>((size_t)ab[mb] + (size_t)G::pimm(j));
     };
-    {
-        auto all = [&](auto... MBc) __attribute__((always_inline)) { (pread(std::integral_constant<int, 0>{}, MBc), ...); };
-        all(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
-            std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
-            std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{},
-            std::integral_constant<int, 12>{});
-    }
+    auto preads = [&](auto Jc) __attribute__((always_inline)) {
+        d3i_unroll([&](auto MBc) __attribute__((always_inline)) { pread(Jc, MBc); }, std::make_integer_sequence<int, NB>{});
+    };
+    preads(std::integral_constant<int, 0>{});
     // BN constants of the wave's two channel-block pairs: requested in the last three K-halves, in place of the weight look-ahead that has
     // nothing left to fetch
     f32x4 es[2][2], eh[2][2];
     const int chw = chTile * G::BM + wave * G::CW + 8 * fq;          // this lane's channels of pair g: chw + 32 g .. + 7
     auto step = [&](auto Rc, auto Jc) __attribute__((always_inline)) {
         constexpr int r = decltype(Rc)::value, j = decltype(Jc)::value, kh = r * G::JR + j;
-        constexpr int stg = (r == 0 && j < 18) ? j / 6 + 1 : 0;       // filter row 0: slice stg is fetched in K-half 6 (stg - 1), written in + 3, visible behind + 4
-        auto reads = [&](auto... MBc) __attribute__((always_inline)) { (pread(std::integral_constant<int, j + 1>{}, MBc), ...); };
-        if constexpr ((D3I_DBG & 1) == 0)
-            reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
-                  std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
-                  std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{},
-                  std::integral_constant<int, 12>{});
+        constexpr int stg = (r == 0 && j < 6 * (G::SLICES - 1)) ? j / 6 + 1 : 0;       // filter row 0: slice stg is fetched in K-half 6 (stg - 1), written in + 3, visible behind + 4
+        constexpr bool ahead = CIN == 256 || kh + 1 < G::KH;          // (512: no grid row behind the last one for the last K-half's look-ahead reads)
+        if constexpr ((D3I_DBG & 1) == 0 && ahead)
+            preads(std::integral_constant<int, j + 1>{});
         if constexpr (kh + G::PFW < G::KH) {
             if constexpr ((D3I_DBG & 2) == 0) wload(kh + G::PFW, std::integral_constant<int, (j + G::PFW) % G::WRING>{});
         } else if constexpr (kh + G::PFW == G::KH) {
@@ -191,9 +224,9 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
         for (int mb = 0; mb < NB; ++mb) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (mb % 3 == 1 && mb / 3 < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (stg > 0 && j % 6 == 0 && mb < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (stg > 0 && j % 6 == 3 && mb < 8) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if ((mb + 1) * 4 / NB != mb * 4 / NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (stg > 0 && j % 6 == 0 && mb < G::SPT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (stg > 0 && j % 6 == 3 && mb < G::SPT) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (stg > 0 && j % 6 == 4) {                        // every wave's pieces of slice stg are in LDS before anybody requests its fragments (K-half j + 1)
@@ -202,13 +235,7 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
         }
     };
     auto row = [&](auto Rc) __attribute__((always_inline)) {
-        auto steps = [&](auto... Jc) __attribute__((always_inline)) { (step(Rc, Jc), ...); };
-        steps(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{},
-              std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{}, std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{},
-              std::integral_constant<int, 8>{}, std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{},
-              std::integral_constant<int, 12>{}, std::integral_constant<int, 13>{}, std::integral_constant<int, 14>{}, std::integral_constant<int, 15>{},
-              std::integral_constant<int, 16>{}, std::integral_constant<int, 17>{}, std::integral_constant<int, 18>{}, std::integral_constant<int, 19>{},
-              std::integral_constant<int, 20>{}, std::integral_constant<int, 21>{}, std::integral_constant<int, 22>{}, std::integral_constant<int, 23>{});
+        d3i_unroll([&](auto Jc) __attribute__((always_inline)) { step(Rc, Jc); }, std::make_integer_sequence<int, G::JR>{});
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) ab[mb] += (uint32_t)G::ROWB;
 #ifdef D3I_CYCLES
@@ -235,7 +262,7 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
 #pragma unroll
             for (int mb = 0; mb < NB; ++mb) {
                 const int pix = 16 * mb + fr, ch0 = chw + 32 * g;
-                const uint32_t roff = (ch0 < p.Cout && pix < HW) ? (uint32_t)(((mImg + pix) * p.Cout + ch0) * 2) : 0x80000000u;
+                const uint32_t roff = (ch0 < p.Cout && pix < NP) ? (uint32_t)(((mImg + pix) * p.Cout + ch0) * 2) : 0x80000000u;
                 rr[g][mb] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
             }
     }
@@ -272,7 +299,7 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
                 o[e] = pack2<DT>(v0, v1);
             }
             const int pix = 16 * mb + fr;
-            const uint32_t boff = (chok && pix < HW) ? (uint32_t)(((mImg + pix) * p.Ypitch + ch0) * 2) : 0x80000000u;     // (the host keeps y below 2 GiB)
+            const uint32_t boff = (chok && pix < NP) ? (uint32_t)(((mImg + pix) * p.Ypitch + ch0) * 2) : 0x80000000u;     // (the host keeps y below 2 GiB)
             __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
         }
     };
@@ -291,10 +318,10 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
 }
 #endif  // __HIP_DEVICE_COMPILE__
 
-template <int DT>
+template <int DT, int CIN>
 __global__ __launch_bounds__(256, 1) void d3i_kernel(const D3Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    d3i_body<DT>(p, smem);
+    d3i_body<DT, CIN>(p, smem);
 #endif  // __HIP_DEVICE_COMPILE__
 }

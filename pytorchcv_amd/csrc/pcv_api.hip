@@ -52,8 +52,10 @@ extern template __global__ void d3c_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3c_kernel<PCV_F16>(const D3Params);
 extern template __global__ void d3k_kernel<PCV_BF16>(const D3Params);
 extern template __global__ void d3k_kernel<PCV_F16>(const D3Params);
-extern template __global__ void d3i_kernel<PCV_BF16>(const D3Params);
-extern template __global__ void d3i_kernel<PCV_F16>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_BF16, 256>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_F16, 256>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_BF16, 512>(const D3Params);
+extern template __global__ void d3i_kernel<PCV_F16, 512>(const D3Params);
 #define P1R_DECLARE(CW, CIN)                                                       \
     extern template __global__ void p1r_kernel<PCV_BF16, CW, CIN>(const D3Params); \
     extern template __global__ void p1r_kernel<PCV_F16, CW, CIN>(const D3Params);
@@ -79,7 +81,7 @@ struct pcv_ctx {
     unsigned long long dbg_ptr = 0;   // diagnostic builds (-DD3X3_STAMPS): device buffer for in-kernel stamps ("dbg_lo" / "dbg_hi")
     int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3k = -1;           // 128-input-channel dense 3x3 kernel on 28-wide maps (d3k_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
-    int use_d3i = -1;           // 256-input-channel dense 3x3 kernel with the image in LDS (d3i_conv.hpp; maps up to 14 x 14): -1 = where it applies and half-fills the chip, 0 = never, 1 = wherever it applies
+    int use_d3i = -1;           // dense 3x3 kernel with the image(s) in LDS (d3i_conv.hpp; 256 input channels on maps up to 14 x 14, 512 up to 7 x 7): -1 = where it applies and fills 3/4 of the chip, 0 = never, 1 = wherever it applies
     int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
@@ -147,7 +149,7 @@ struct ConvPlan {
     size_t ktab_bytes = 0, w_bytes = 0, total_bytes = 0;
     int gconv_kt = 5;         // K-steps per slab of that blob: 5 (tap pairs x 16 channels; 4/8/16 channels per group) or 9 (taps x 32 channels)
     bool gconv = false;       // grouped 3x3/p1, stride 1 or 2, 4/8/16/32 channels per group: a second blob for gconv3x3(r).hpp follows the generic
-    bool d3i = false;         // dense 3x3/s1/p1, 16 bit, 256 input channels, Cout % 64 == 0: a fragment-ordered copy of the weights for d3i_conv.hpp
+    bool d3i = false;         // dense 3x3/s1/p1, 16 bit, 256 / 512 input channels, Cout % 64 == 0: a fragment-ordered copy of the weights for d3i_conv.hpp
     size_t d3i_off = 0;       // follows the generic blob (whether a launch takes that kernel depends on the map size)
     size_t gconv_off = 0;     // one (the choice between the two kernels depends on the map width, known only at launch)
     std::vector<uint32_t> ktab;   // built only when tables == true
@@ -247,11 +249,11 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
         P.gconv_off = (P.total_bytes + 15) / 16 * 16;
         P.total_bytes = P.gconv_off + (size_t)(d.Cin / 16) * P.gconv_kt * 16 * 32 * P.ES;
     }
-    P.d3i = P.conv3 && P.ES == 2 && d.Cin == D3ICfg::CIN && d.Cout % D3ICfg::CW == 0 && d.out_dtype == d.dtype &&
-            P.wrows >= d.Cout && P.Kpad == 9 * D3ICfg::CIN;
+    P.d3i = P.conv3 && P.ES == 2 && (d.Cin == 256 || d.Cin == 512) && d.Cout % D3ICfg::CW == 0 && d.out_dtype == d.dtype &&
+            P.wrows >= d.Cout && P.Kpad == 9 * d.Cin;
     if (P.d3i) {
         P.d3i_off = (P.total_bytes + 15) / 16 * 16;
-        P.total_bytes = P.d3i_off + (size_t)(d.Cout / D3ICfg::CW) * D3ICfg::WBYTES;
+        P.total_bytes = P.d3i_off + (size_t)(d.Cout / D3ICfg::CW) * (d.Cin == 256 ? D3ICfgT<256>::WBYTES : D3ICfgT<512>::WBYTES);
     }
     if (P.w_bytes >= 0x80000000ull) return "packed weights exceed 2 GiB";
 
@@ -476,7 +478,8 @@ static const int kD1Count = (int)(sizeof(kD1) / sizeof(kD1[0]));
 static const D3Shape kD3W[] = {D3W_SHAPES(D3W_ROW, 0) D3WT_SHAPES(D3WT_ROW, 0)};
 static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
-static const void* kD3I[2] = {reinterpret_cast<const void*>(d3i_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16>)};
+static const void* kD3I[2][2] = {{reinterpret_cast<const void*>(d3i_kernel<PCV_BF16, 256>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16, 256>)},
+                                 {reinterpret_cast<const void*>(d3i_kernel<PCV_BF16, 512>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16, 512>)}};
 static const void* kD3K[2] = {reinterpret_cast<const void*>(d3k_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3k_kernel<PCV_F16>)};
 // p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels), [2] 256 input channels with
 // 32 channels per wave (a skip tensor, or fewer than 384 output channels)
@@ -489,7 +492,8 @@ static int enable_d3x3(pcv_ctx* ctx) {
         for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3K[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3KCfg::LDS));
-    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfg::LDS));
+    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[0][t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfgT<256>::LDS));
+    for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[1][t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfgT<512>::LDS));
     for (int i = 0; i < kD3WCount; ++i)
         for (int t = 0; t < 2; ++t)
             HIP_TRY(ctx, hipFuncSetAttribute(kD3W[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kD3W[i].lds));
@@ -1118,7 +1122,7 @@ int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* pa
         else pack_gconv_kernel<PCV_F16><<<ggrid, 256, 0, s>>>(w, gout, d->Cin, P.Cg_in);
     }
     if (P.d3i) {
-        const int total = d->Cout / D3ICfg::CW * (D3ICfg::WBYTES / 16);
+        const int total = (int)((P.total_bytes - P.d3i_off) / 16);
         pack_d3i_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(reinterpret_cast<const u32x4*>(pp.out),
                                                                         reinterpret_cast<u32x4*>(static_cast<char*>(packed) + P.d3i_off), P.Kpad, total);
     }
@@ -1201,7 +1205,7 @@ enum ConvKernel {
     CK_STEM,        // stem_conv.hpp: Cin <= 4, stride 2 (+ fused max-pool, + fp32 NCHW input)
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
-    CK_D3I,         // d3i_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 256 input channels on maps up to 14 x 14 (image in LDS, weights straight to registers)
+    CK_D3I,         // d3i_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 256 input channels on maps up to 14 x 14 or 512 up to 7 x 7 (image(s) in LDS, weights straight to registers)
     CK_D3K,         // d3k_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 128 input channels on 28-wide maps (weights in registers / AGPRs)
     CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
@@ -1298,10 +1302,14 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
         // 256 input channels on a map of up to 14 x 14 (ResNet stage 3): one image x 256 channels per block; automatic choice for (almost)
         // full 13-block images from three quarters of a round of the CUs up (rocprofv3, batch 256 / 128: 47.6 / 39.9 us against d3w 59.0 /
         // d3q 34.9 - a block takes ~40 us however few there are)
+        // 512 input channels on a map of up to 7 x 7 (stage 4): two images x 256 channels per block
+        const int d3i_maxw = d->Cin == 256 ? D3ICfgT<256>::MAXW : D3ICfgT<512>::MAXW, d3i_nimg = d->Cin == 256 ? 1 : 2;
         if (P.d3i && ctx->use_d3i != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3i > 0) && (ctx->use_d3w <= 0 || ctx->use_d3i > 0) &&
-            d->H <= D3ICfg::MAXW && d->W <= D3ICfg::MAXW && G.cpitch == d->Cin && G.wpitch == d->W) {
-            const long long tiles = (long long)((d->Cout + D3ICfg::BM - 1) / D3ICfg::BM) * d->N;
-            if (ctx->use_d3i > 0 || (d->H * d->W > 16 * (D3ICfg::NBLK - 1) - 16 && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D3I; return R; }
+            d->H <= d3i_maxw && d->W <= d3i_maxw && G.cpitch == d->Cin && G.wpitch == d->W) {
+            const long long tiles = (long long)((d->Cout + D3ICfg::BM - 1) / D3ICfg::BM) * ((d->N + d3i_nimg - 1) / d3i_nimg);
+            // (almost) full pixel blocks: more than 12 of 13 / 6 of 7 blocks' worth of pixels
+            const bool full = d3i_nimg * d->H * d->W > 16 * ((d->Cin == 256 ? D3ICfgT<256>::NBLK : D3ICfgT<512>::NBLK) - 1) - 16;
+            if (ctx->use_d3i > 0 || (full && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D3I; return R; }
         }
         if (ctx->use_d3w != 0 && (ctx->use_d3x3 < 0 || ctx->use_d3w > 0)) {       // ("d3x3" forced to a shape: that kernel, for its tests)
             R.shape = ctx->use_d3w > 0 ? std::min(ctx->use_d3w - 1, kD3WCount - 1)
@@ -1528,12 +1536,14 @@ static int launch_d3i(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     q.nk = P.nk; q.slices = d->Cin / 64;
     q.act = d->act; q.post_act = d->post_act;
     q.nChTiles = (d->Cout + D3ICfg::BM - 1) / D3ICfg::BM;
-    const long long nT = (long long)d->N * q.nChTiles;
+    const int wide = d->Cin == 256 ? 0 : 1, nimg = wide ? D3ICfgT<512>::NIMG : D3ICfgT<256>::NIMG;
+    const long long nT = (long long)((d->N + nimg - 1) / nimg) * q.nChTiles;
     if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
     q.nTiles = (int)nT;
     q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);       // (diagnostic builds: -DD3I_CYCLES)
     void* args[] = {&q};
-    HIP_TRY(ctx, hipLaunchKernel(kD3I[d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nT), dim3(D3ICfg::THREADS), args, (size_t)D3ICfg::LDS, A.stream));
+    HIP_TRY(ctx, hipLaunchKernel(kD3I[wide][d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nT), dim3(D3ICfg::THREADS), args,
+                                 (size_t)(wide ? D3ICfgT<512>::LDS : D3ICfgT<256>::LDS), A.stream));
     return PCV_OK;
 }
 

@@ -664,25 +664,28 @@ def test_conv3x3_c128_kernel_equals_generic_and_oracle(shape, dtype, grid, cuda_
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
-_D3I_SHAPES = [  # (N, Cout, H, W, residual): 256 input channels on maps up to 14 x 14 (csrc/d3i_conv.hpp: the image in LDS, one block per image)
-    (3, 256, 14, 14, False), (2, 256, 14, 14, True), (2, 512, 14, 14, True), (3, 192, 13, 14, True), (2, 64, 14, 11, False), (5, 320, 7, 7, True),
-    (1, 256, 1, 1, False), (2, 128, 3, 14, True), (9, 256, 14, 1, False),
+_D3I_SHAPES = [  # (N, Cin, Cout, H, W, residual): 256 input channels on maps up to 14 x 14 (csrc/d3i_conv.hpp: the image in LDS, one block per
+    # image), 512 on maps up to 7 x 7 (two images per block: even and odd batches)
+    (3, 256, 256, 14, 14, False), (2, 256, 256, 14, 14, True), (2, 256, 512, 14, 14, True), (3, 256, 192, 13, 14, True), (2, 256, 64, 14, 11, False),
+    (5, 256, 320, 7, 7, True), (1, 256, 256, 1, 1, False), (2, 256, 128, 3, 14, True), (9, 256, 256, 14, 1, False),
+    (4, 512, 512, 7, 7, False), (5, 512, 512, 7, 7, True), (1, 512, 256, 7, 7, True), (3, 512, 192, 6, 7, True), (2, 512, 64, 7, 5, False),
+    (7, 512, 320, 4, 4, True), (3, 512, 512, 1, 1, False), (2, 512, 128, 2, 7, True),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", _D3I_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D3I_SHAPES])
 def test_conv3x3_c256_kernel_equals_generic_and_oracle(shape, dtype, cuda_device):
-    """d3i_kernel (256 input channels, maps up to 14 x 14: ResNet stage 3, reference resnet.py:49,56,120-127): bit-identical to the generic
-    implicit GEMM (same K order, same MFMA chain per accumulator; its weights come from a fragment-ordered copy of the packed blob) on full
-    14 x 14 images, smaller and non-square maps (zero frame / unused pixel blocks), one / two / ragged channel tiles (64 .. 512 output
-    channels), with and without the residual epilogue; and within the 16-bit bound of the quantisation-matched oracle."""
+    """d3i_kernel (256 input channels on maps up to 14 x 14, 512 on maps up to 7 x 7: ResNet stages 3 and 4, reference resnet.py:49,56,
+    120-127): bit-identical to the generic implicit GEMM (same K order, same MFMA chain per accumulator; its weights come from a
+    fragment-ordered copy of the packed blob) on full images, smaller and non-square maps (zero frame / unused pixel blocks), one / two /
+    ragged channel tiles (64 .. 512 output channels), even and odd batches (the 512-channel form holds two images per block), with and
+    without the residual epilogue; and within the 16-bit bound of the quantisation-matched oracle."""
     import pytorchcv_amd
     from pytorchcv_amd import engine
     from pytorchcv_amd.models.common.conv import conv3x3_block
     from oracle import refnet
-    N, Cout, H, W, use_res = shape
-    C = 256
+    N, C, Cout, H, W, use_res = shape
     blk = conv3x3_block(in_channels=C, out_channels=Cout).eval()
     sd = util.synth_state_dict(blk.state_dict(), seed=83)
     blk.load_state_dict(sd)
@@ -708,6 +711,7 @@ _RW_KERNELS = {  # kernel -> (ConvBlock factory name, input channels, H, W, tuni
     "d3c": ("conv3x3_block", 64, 12, 56, "d3c", {"d3x3": 0}),
     "d3k": ("conv3x3_block", 128, 12, 28, "d3k", {"d3x3": 0}),
     "d3i": ("conv3x3_block", 256, 14, 14, "d3i", {"d3x3": 0}),
+    "d3i512": ("conv3x3_block", 512, 7, 7, "d3i", {"d3x3": 0}),
     "p1r": ("conv1x1_block", 512, 14, 14, "p1r", {"d1x1": 0}),
     "p1r256": ("conv1x1_block", 256, 14, 14, "p1r", {"d1x1": 0}),
 }
