@@ -51,6 +51,13 @@ template <int CIN_> struct D3ICfgT {
     static constexpr int PFW = 3, WRING = 4;                 // weights: K-halves of look-ahead, ring slots
     static constexpr int WBYTES = KH * 4 * 1024;             // the fragment-ordered weights of one wave (64 channels)
     static constexpr int SPT = (NSLOT * 8 + THREADS - 1) / THREADS;  // staging pieces (16 B of a 64-channel slice) per thread: 8 / 5
+    // Staging schedule. Slices 0 .. LEAD - 1 are staged in the prologue; slice s >= LEAD is requested in K-half 6 (s - LEAD) of filter row 0 and
+    // written to LDS SDIST K-halves later, 2 K-halves before its first fragment is requested: the HBM latency under every CU's simultaneous
+    // requests (~2 us) must fit into SDIST K-halves (832 / 448 matrix-pipe cycles each), or the weight loads queued behind the staging loads
+    // (vmcnt retires in order) stall the MFMAs - with SDIST = 3 that cost 1 100 cycles per slice. 256: one register buffer (the registers are
+    // full), 5 K-halves; 512: two buffers, 11 K-halves.
+    static constexpr int LEAD = CIN == 256 ? 2 : 3, SBUF = CIN == 256 ? 1 : 2, SDIST = CIN == 256 ? 5 : 11;
+    static_assert(6 * LEAD - SDIST >= 2 && SDIST < 6 * SBUF, "a slice is in LDS before its first fragment read is issued; its buffer is free again by then");
     static_assert(JR % WRING == 0 && JR % 2 == 0, "ring slots are compile-time inside the filter-row loop");
     // byte offset of K-half j = (slice, filter column, half) of a filter row behind a window's top-left slot (j >= JR: the next row's)
     static constexpr int pimm(int j) { return (j >= JR ? ROWB : 0) + (((j % JR) % 6) >> 1) * PITCH + ((j % JR) / 6) * 128 + (j & 1) * 64; }
@@ -118,7 +125,7 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     // ---- the image(s): NSLOT slots x 16-byte pieces, SPT per thread and 64-channel slice. Frame slots and slots outside an H x W map smaller
     // than the grid are out of range: zeros. Slice 0 is staged here; the others arrive under the MFMAs of filter row 0, whose K-halves
     // 6 g .. 6 g + 5 read slice g. ----
-    u32x4 sb[G::SPT];
+    u32x4 sb[G::SBUF][G::SPT];
     uint32_t soff[CIN == 256 ? 1 : G::SPT];
     uint32_t slds;
     const int sc8 = tid & 7;
@@ -140,23 +147,28 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
         slds = lds0 + (uint32_t)((tid >> 3) * G::PITCH + sc8 * 16);
     }
     const uint32_t srow2 = (uint32_t)(2 * W * G::CIN * 2);         // (256: two map rows)
-    auto sload = [&](int g) __attribute__((always_inline)) {
+    auto sload = [&](int g, u32x4 (&buf)[G::SPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < G::SPT; ++i)
-            sb[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (CIN == 256 ? soff[0] + (uint32_t)i * srow2 : soff[CIN == 256 ? 0 : i]) + (uint32_t)(g * 128), 0, 0);
+            buf[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (CIN == 256 ? soff[0] + (uint32_t)i * srow2 : soff[CIN == 256 ? 0 : i]) + (uint32_t)(g * 128), 0, 0);
     };
-    auto swrite = [&](int g) __attribute__((always_inline)) {
+    auto swrite = [&](int g, const u32x4 (&buf)[G::SPT]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < G::SPT; ++i) {
             if constexpr (CIN == 256) {
-                *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(2 * i * G::ROWB + g * 128))) = sb[i];
+                *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(2 * i * G::ROWB + g * 128))) = buf[i];
             } else {
-                if (32 * i + (tid >> 3) < G::NSLOT) *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(32 * i * G::PITCH + g * 128))) = sb[i];
+                if (32 * i + (tid >> 3) < G::NSLOT) *reinterpret_cast<lds_wptr>((size_t)(slds + (uint32_t)(32 * i * G::PITCH + g * 128))) = buf[i];
             }
         }
     };
-    sload(0);
-    swrite(0);
+    {
+        u32x4 pb[G::LEAD][G::SPT];                                // (the prologue's own registers: every slice in flight at once)
+#pragma unroll
+        for (int g = 0; g < G::LEAD; ++g) sload(g, pb[g]);
+#pragma unroll
+        for (int g = 0; g < G::LEAD; ++g) swrite(g, pb[g]);
+    }
 
     // ---- fragment addresses: block mb's lane pixel p = 16 mb + fr (image p / HW, its pixel p % HW) at the window's top-left slot (filter row
     // r, column q: + (GW r + q) slots); pixels behind the block's images read slot 0 (zeros; never stored) ----
@@ -198,8 +210,14 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     const int chw = chTile * G::BM + wave * G::CW + 8 * fq;          // this lane's channels of pair g: chw + 32 g .. + 7
     auto step = [&](auto Rc, auto Jc) __attribute__((always_inline)) {
         constexpr int r = decltype(Rc)::value, j = decltype(Jc)::value, kh = r * G::JR + j;
-        constexpr int stg = (r == 0 && j < 6 * (G::SLICES - 1)) ? j / 6 + 1 : 0;       // filter row 0: slice stg is fetched in K-half 6 (stg - 1), written in + 3, visible behind + 4
+        // filter row 0: slice sf is requested in this K-half, slice sw (requested SDIST K-halves ago) is written behind it and visible after the barrier
+        constexpr int sf = (r == 0 && j % 6 == 0 && j / 6 + G::LEAD < G::SLICES) ? j / 6 + G::LEAD : 0;
+        constexpr int sw = (r == 0 && j >= G::SDIST && (j - G::SDIST) % 6 == 0 && (j - G::SDIST) / 6 + G::LEAD < G::SLICES) ? (j - G::SDIST) / 6 + G::LEAD : 0;
         constexpr bool ahead = CIN == 256 || kh + 1 < G::KH;          // (512: no grid row behind the last one for the last K-half's look-ahead reads)
+        // (a K-half that writes a slice: the writes come FIRST in program order. LDS writes and reads may alias as far as the compiler knows, so
+        // their order is kept - with the reads first no write could stand between two of them, the issue pattern below had no solution and
+        // the scheduler fell back to MFMAs | reads | writes | barrier in a row: 1 100 cycles per slice)
+        if constexpr (sw > 0) swrite(sw, sb[sw % G::SBUF]);
         if constexpr ((D3I_DBG & 1) == 0 && ahead)
             preads(std::integral_constant<int, j + 1>{});
         if constexpr (kh + G::PFW < G::KH) {
@@ -212,24 +230,30 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
                 eh[g][0] = *reinterpret_cast<const f32x4*>(p.shift + chl); eh[g][1] = *reinterpret_cast<const f32x4*>(p.shift + chl + 4);
             }
         }
-        if constexpr (stg > 0 && j % 6 == 0) sload(stg);
-        if constexpr (stg > 0 && j % 6 == 3) swrite(stg);
+        if constexpr (sf > 0) sload(sf, sb[sf % G::SBUF]);
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
                 acc[mb][nb] = Mma<DT>::run(Wf[(D3I_DBG & 2) ? 0 : j % G::WRING][nb], Pf[(D3I_DBG & 1) ? 0 : (j & 1)][mb], acc[mb][nb]);
-        // issue order: four MFMAs, one fragment read; a weight load behind every third read; a staging load / write behind each of the first eight
-#pragma unroll
-        for (int mb = 0; mb < NB; ++mb) {
+        // issue order: four MFMAs, one fragment read; a weight load behind every third read; a staging load behind each of the first SPT.
+        // A K-half that writes a slice: the SPT writes one by one, then the NB reads over the remaining gaps.
+        d3i_unroll([&](auto MBc) __attribute__((always_inline)) {
+            constexpr int mb = decltype(MBc)::value;
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if ((mb + 1) * 4 / NB != mb * 4 / NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (stg > 0 && j % 6 == 0 && mb < G::SPT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (stg > 0 && j % 6 == 3 && mb < G::SPT) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
+            if constexpr (sw == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            } else if constexpr (mb < G::SPT) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            } else {
+                constexpr int RG = NB - G::SPT;
+                __builtin_amdgcn_sched_group_barrier(0x100, (NB * (mb - G::SPT + 1)) / RG - (NB * (mb - G::SPT)) / RG, 0);
+            }
+            if constexpr ((mb + 1) * 4 / NB != mb * 4 / NB) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if constexpr (sf > 0 && mb < G::SPT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }, std::make_integer_sequence<int, NB>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (stg > 0 && j % 6 == 4) {                        // every wave's pieces of slice stg are in LDS before anybody requests its fragments (K-half j + 1)
+        if constexpr (sw > 0) {                                       // every wave's pieces of slice sw are in LDS before anybody requests its fragments (two K-halves on)
             __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
             d3q_sync();
         }
@@ -266,8 +290,10 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
                 rr[g][mb] = __builtin_amdgcn_raw_buffer_load_b128(rrsrc, roff, 0, 0);
             }
     }
-    auto half = [&](auto HRc, auto Gc) __attribute__((always_inline)) {
-        constexpr bool HR = decltype(HRc)::value;
+    // ROc: the ResNet forms - ReLU only (no skip tensor), or no activation + skip tensor + ReLU - as one v_maximum3 per value; the general form
+    // clamps to launch-uniform bounds (two instructions per clamp, infinite bounds included). Same values either way.
+    auto half = [&](auto HRc, auto ROc, auto Gc) __attribute__((always_inline)) {
+        constexpr bool HR = decltype(HRc)::value, RO = decltype(ROc)::value;
         constexpr int g = decltype(Gc)::value;
         const int ch0 = chw + 32 * g;
         const bool chok = ch0 < p.Cout;
@@ -282,7 +308,16 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
                 const f32x4& sc = hf == 0 ? es0 : es1;
                 const f32x4& sh = hf == 0 ? eh0 : eh1;
                 float v0 = a[k0] * sc[k0] + sh[k0], v1 = a[k0 + 1] * sc[k0 + 1] + sh[k0 + 1];
-                if constexpr (HR) {
+                if constexpr (RO) {
+                    if constexpr (HR) {
+                        float lo, hi;
+                        unpack2<DT>(rr[g][mb][e], lo, hi);
+                        v0 += lo;
+                        v1 += hi;
+                    }
+                    v0 = __builtin_elementwise_maximum(v0, 0.f);
+                    v1 = __builtin_elementwise_maximum(v1, 0.f);
+                } else if constexpr (HR) {
                     v0 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, alo), ahi);
                     v1 = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v1, alo), ahi);
                     float lo, hi;
@@ -303,8 +338,14 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
             __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, boff, 0, 0);
         }
     };
-    if (has_res) { half(std::true_type{}, std::integral_constant<int, 0>{}); half(std::true_type{}, std::integral_constant<int, 1>{}); }
-    else { half(std::false_type{}, std::integral_constant<int, 0>{}); half(std::false_type{}, std::integral_constant<int, 1>{}); }
+    const bool relu_only = has_res ? (p.act == PCV_ACT_NONE && p.post_act == PCV_ACT_RELU)
+                                   : ((p.act == PCV_ACT_RELU && p.post_act <= PCV_ACT_RELU) || (p.act == PCV_ACT_NONE && p.post_act == PCV_ACT_RELU));
+    auto both = [&](auto HRc, auto ROc) __attribute__((always_inline)) {
+        half(HRc, ROc, std::integral_constant<int, 0>{});
+        half(HRc, ROc, std::integral_constant<int, 1>{});
+    };
+    if (has_res) { if (relu_only) both(std::true_type{}, std::true_type{}); else both(std::true_type{}, std::false_type{}); }
+    else { if (relu_only) both(std::false_type{}, std::true_type{}); else both(std::false_type{}, std::false_type{}); }
     guard.commit(p.ovf);
 #ifdef D3I_CYCLES
     __builtin_amdgcn_s_waitcnt(0x0070);

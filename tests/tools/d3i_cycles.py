@@ -9,13 +9,15 @@ from pytorchcv_amd.models.common.conv import conv3x3_block
 from pytorchcv_amd.synth import synth_state_dict
 dev = torch.device("cuda", 0); ctx = _lib.ctx_for(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-dbg = torch.zeros(N * 4 * 8, dtype=torch.int32, device=dev)
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 256          # 256: 14 x 14 maps, 512: 7 x 7
+HW = 14 if C == 256 else 7
+dbg = torch.zeros(N * 4 * 8 * 2, dtype=torch.int32, device=dev)
 def tune(k, v): _lib.check(_lib.lib().pcv_set_tuning(ctx, k.encode(), ctypes.c_int(v).value), ctx)
 ptr = dbg.data_ptr(); tune("dbg_lo", ctypes.c_int32(ptr & 0xFFFFFFFF).value); tune("dbg_hi", ctypes.c_int32(ptr >> 32).value)
-blk = conv3x3_block(in_channels=256, out_channels=256).eval()
+blk = conv3x3_block(in_channels=C, out_channels=C).eval()
 blk.load_state_dict(synth_state_dict(blk.state_dict(), seed=1))
 blk = pytorchcv_amd.set_compute_dtype(blk.to(dev), "bf16")
-x = engine.NHWC(torch.randn(N, 14, 14, 256, device=dev).to(torch.bfloat16), N, 14, 14, 256)
+x = engine.NHWC(torch.randn(N, HW, HW, C, device=dev).to(torch.bfloat16), N, HW, HW, C)
 tune("d3i", 1)
 with torch.no_grad():
     for _ in range(10): blk(x)
