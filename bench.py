@@ -61,7 +61,9 @@ RIDGE_FLOP_PER_BYTE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)     # 312.5
 def kernel_class_of(name: str):
     """Kernel class of a rocprofv3 kernel name, None for kernels outside the convolution path (pools, head, layout, torch)."""
     head = name.split("(")[0].rstrip()
-    if "d3w_kernel" in name or "d3c_kernel" in name or "d3k_kernel" in name:
+    if "pack_" in name:
+        return None
+    if "d3w_kernel" in name or "d3c_kernel" in name or "d3k_kernel" in name or "d3i_kernel" in name:
         return "dense3x3"
     if "p1r_kernel" in name:
         return "dense1x1_kheavy"

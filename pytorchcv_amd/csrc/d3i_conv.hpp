@@ -66,7 +66,7 @@ template <int CIN_> struct D3ICfgT {
 };
 typedef D3ICfgT<256> D3ICfg;
 
-// Timing experiments (tests/tools/sh/d3i_variants.sh; results are WRONG with a bit set): 1 = no fragment reads in the K loop, 2 = no weight
+// Timing experiments (tests/tools/sh/kernel_variants.sh; results are WRONG with a bit set): 1 = no fragment reads in the K loop, 2 = no weight
 // loads in the K loop. -DD3I_CYCLES: shader-cycle stamps per wave into p.dbg (tests/tools/d3i_cycles.py).
 #ifndef D3I_DBG
 #define D3I_DBG 0

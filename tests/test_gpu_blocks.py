@@ -713,6 +713,7 @@ _RW_KERNELS = {  # kernel -> (ConvBlock factory name, input channels, H, W, tuni
     "d3i": ("conv3x3_block", 256, 14, 14, "d3i", {"d3x3": 0}),
     "d3i512": ("conv3x3_block", 512, 7, 7, "d3i", {"d3x3": 0}),
     "p1r": ("conv1x1_block", 512, 14, 14, "p1r", {"d1x1": 0}),
+    "d1i": ("conv1x1_block", 1024, 14, 14, "d1i", {"d1x1": 0, "d1i": 0}),
     "p1r256": ("conv1x1_block", 256, 14, 14, "p1r", {"d1x1": 0}),
 }
 
@@ -730,7 +731,7 @@ def test_register_weight_kernels_epilogue_variants_equal_generic(kernel, variant
     from pytorchcv_amd.models.common import conv as convmod
     from pytorchcv_amd.models.common.activ import create_activation_layer
     ctor, C, H, W, key, generic = _RW_KERNELS[kernel]
-    Cout = 256 if kernel.startswith("p1r") else C
+    Cout = 256 if kernel.startswith("p1r") or kernel == "d1i" else C
     act = "relu6" if variant.startswith("relu6") else None if variant.startswith("none") else "relu"
     use_res = "+res" in variant
     post = {"relu6+res+relu6": torch.nn.ReLU6(), "none+res+relu": torch.nn.ReLU()}.get(variant)
@@ -839,6 +840,46 @@ def test_conv1x1_register_weights_kernel_equals_generic_and_oracle(shape, dtype,
         y = engine.to_nchw(yh).cpu()
     q = refnet.Quant(dtype)
     ref = refnet.conv_block(sd, "", q.r(x), stride=stride, q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
+    d = (y - ref).abs()
+    assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
+
+
+_D1I_SHAPES = [  # (N, Cin, Cout, H, W, residual): 512 / 1024 / 2048 input channels at stride 1 (csrc/d1i_conv.hpp: activations streamed through
+    # LDS in 64-channel slices, weights straight from L2): whole and partial 208-pixel tiles, one to four / ragged channel tiles
+    (3, 1024, 512, 14, 14, False), (4, 512, 1024, 14, 14, True), (5, 2048, 1024, 7, 7, False), (2, 1024, 256, 14, 14, True), (1, 1024, 2048, 7, 7, True),
+    (1, 512, 64, 13, 16, False), (2, 2048, 512, 7, 7, True), (1, 1024, 320, 1, 1, False), (3, 512, 192, 9, 23, True), (2, 1024, 1024, 20, 21, False),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", _D1I_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D1I_SHAPES])
+def test_conv1x1_streamed_kernel_equals_generic_and_oracle(shape, dtype, cuda_device):
+    """d1i_kernel (1x1 / stride 1 with 512 / 1024 / 2048 input channels: ResBottleneck / ResNeXtBottleneck conv1 and conv3, reference
+    resnet.py:108-131, resnext.py:56-75): bit-identical to the generic implicit GEMM (same K order, same MFMA chain per accumulator; weights
+    from the fragment-ordered copy of the packed blob, activations through a four-slice LDS ring) on whole and partial pixel tiles, one to
+    four and ragged channel tiles, with and without the residual epilogue; and within the 16-bit bound of the quantisation-matched oracle."""
+    import pytorchcv_amd
+    from pytorchcv_amd import engine
+    from pytorchcv_amd.models.common.conv import conv1x1_block
+    from oracle import refnet
+    N, C, Cout, H, W, use_res = shape
+    blk = conv1x1_block(in_channels=C, out_channels=Cout).eval()
+    sd = util.synth_state_dict(blk.state_dict(), seed=87)
+    blk.load_state_dict(sd)
+    blk = pytorchcv_amd.set_compute_dtype(blk.to(cuda_device), dtype)
+    x = util.synth_input(N, C, H, W, seed=33)
+    res = util.synth_input(N, Cout, H, W, seed=34) if use_res else None
+    with torch.no_grad():
+        xh = engine.from_nchw(x.to(cuda_device), dtype, stem=False)
+        rh = engine.from_nchw(res.to(cuda_device), dtype, stem=False) if use_res else None
+        with util.tuning(d1i=1):
+            yh = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        with util.tuning(d1x1=0, d1i=0):
+            yg = blk(xh, residual=rh, post_act=torch.nn.ReLU() if use_res else None)
+        assert torch.equal(yh.t, yg.t), "d1i differs from the generic implicit GEMM in {} elements".format(int((yh.t != yg.t).sum()))
+        y = engine.to_nchw(yh).cpu()
+    q = refnet.Quant(dtype)
+    ref = refnet.conv_block(sd, "", q.r(x), q=q, residual=q.r(res) if use_res else None, post_act="relu" if use_res else None)
     d = (y - ref).abs()
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 

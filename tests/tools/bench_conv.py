@@ -49,4 +49,4 @@ for (N, C, Co, H, k, s, g, res) in LAYERS:
     print("N%d %dx%d C%d->%d k%d s%d g%d%s:" % (N, H, H, C, Co, k, s, g, " +res" if res else ""), flush=True)
     for v, t in times.items():
         print("    %-12s %7.1f us  %6.0f TF   (min %.1f)" % (v, statistics.median(t), flops / statistics.median(t) / 1e6, min(t)), flush=True)
-tune({"d3x3": -1, "d3w": -1, "d3c": -1, "d3k": -1, "d3i": -1, "p1r": -1, "d1x1": -1, "dbg": 0, "dw_flags": 0, "dw_th": 0})
+tune({"d3x3": -1, "d3w": -1, "d3c": -1, "d3k": -1, "d3i": -1, "d1i": -1, "p1r": -1, "d1x1": -1, "dbg": 0, "dw_flags": 0, "dw_th": 0})

@@ -15,7 +15,7 @@ import contextlib  # noqa: E402
 
 
 # defaults of the pcv_set_tuning switches the tests flip (restored on exit, also when the body raises)
-_TUNING_DEFAULTS = {"max_blocks": 0, "d3x3": -1, "d3w": -1, "d3c": -1, "d3k": -1, "d3i": -1, "p1r": -1, "tile": -1, "wstat": 1, "pair_pb": 2, "wpair": 3, "persist": 1, "head": 1, "mbw": 1, "mbr": 1, "mbr_xl": 1, "d1x1": -1, "gconvr": 1, "mbw_wide": 1, "stem32": 1, "dbg": 0}
+_TUNING_DEFAULTS = {"max_blocks": 0, "d3x3": -1, "d3w": -1, "d3c": -1, "d3k": -1, "d3i": -1, "d1i": -1, "p1r": -1, "tile": -1, "wstat": 1, "pair_pb": 2, "wpair": 3, "persist": 1, "head": 1, "mbw": 1, "mbr": 1, "mbr_xl": 1, "d1x1": -1, "gconvr": 1, "mbw_wide": 1, "stem32": 1, "dbg": 0}
 
 
 @contextlib.contextmanager
