@@ -44,7 +44,13 @@ template <int CIN_> struct D1ICfgT {
 };
 
 // Timing experiments (tests/tools/sh/kernel_variants.sh; results are WRONG with a bit set): 1 = no fragment reads in the K loop, 2 = no weight
-// loads in the K loop, 4 = no activation staging in the K loop, 8 = no barriers in the K loop. -DD1I_CYCLES: shader-cycle stamps per wave.
+// loads in the K loop, 4 = no activation staging in the K loop, 8 = no barriers in the K loop, 16 = every block stages the first tile's pixels
+// (activations from L2). -DD1I_CYCLES: shader-cycle stamps per wave (tests/tools/d1i_cycles.py).
+// Measured (round 5, batch 256, bf16): 1024 -> 512 at 14 x 14: 27.9 us per block = 9.1 K cycles of prologue + 32.2 K of K loop (26.6 K of
+// MFMA) + 8.6 K of epilogue, two rounds of blocks: 64 us against 69 - 74 on d3q's 1x1 mode; with the activations from L2 (bit 16) 55.6 us -
+// vmcnt retires in order, so every weight load (an L2 hit) issued behind a slice's activation loads waits for HBM. Tried against that, both
+// slower (K loop 35.0 K cycles): one fragment register set refilled behind its last reader + a five-K-half weight look-ahead; a 16-entry
+// fragment ring (program order MFMAs | write | read per pixel block) + the same look-ahead.
 #ifndef D1I_DBG
 #define D1I_DBG 0
 #endif
@@ -190,9 +196,9 @@ __device__ __forceinline__ void d1i_body(const D3Params& p, char* smem) {
         }, std::make_integer_sequence<int, NB>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (first && s + 1 < G::SLICES && s >= 1 && (D1I_DBG & 8) == 0) {
-            // the slice's barrier: this wave's writes of slice s + 2 (issued in front of this K-half's 13 reads) and, a fortiori, of slice s + 1
-            // are done; nobody reads slice s + 1 before everybody's pieces of it are in LDS, nobody overwrites column (s + 3) % 4 = slice s - 1
-            // (next slice's writes) before everybody has left slice s - 1
+            // the slice's barrier: this wave's writes of slice s + 1 (a slice old) are done - behind them it has issued more LDS operations than
+            // the counter holds; nobody reads slice s + 1 before everybody's pieces of it are in LDS, nobody overwrites column (s + 3) % 4 =
+            // slice s - 1 (next slice's writes) before everybody has left slice s - 1
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NB) : "memory");
             d3q_sync();
         }

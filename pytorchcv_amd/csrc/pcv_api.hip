@@ -1350,7 +1350,9 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
         // 512 / 1024 / 2048 input channels at stride 1: 208-pixel x 256-channel blocks with the weights straight from L2
         if (P.d1i && ctx->use_d1i != 0 && (ctx->use_d1x1 < 0 || ctx->use_d1i > 0) && G.xbytes < 0x80000000ull) {
             const long long tiles = ((long long)G.M64 + D1ICfgT<512>::BP - 1) / D1ICfgT<512>::BP * ((d->Cout + 255) / 256);
-            if (ctx->use_d1i > 0 || (d->Cin >= 1024 && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D1I; return R; }
+            // automatic: from 1024 input channels, without a skip tensor (its epilogue is exposed: 512 -> 1024 + skip 109 against p1r's 74 us,
+            // 1024 -> 2048 + skip at 7 x 7 equal), from three quarters of a round of the CUs (2048 -> 512 at 7 x 7: 122 tiles, 47 against 37 us)
+            if (ctx->use_d1i > 0 || (d->Cin >= 1024 && !d->has_residual && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D1I; return R; }
         }
         // 256 / 512 input channels: the kernel that keeps the weights in registers, where its tiles fill the chip and (almost) every
         // wave of a channel group has channels to compute
