@@ -1,5 +1,5 @@
-// d1i_conv.hpp - 1x1 / stride 1 convolution with MANY input channels (512 / 1024 / 2048: the K-heavy pointwise layers of the bottleneck
-// networks - ResNeXt-101's 1024 -> 512 and 512 -> 1024 at 14 x 14, the 2048-channel layers at 7 x 7), gfx950 MFMA: d3i_conv.hpp's loop with
+// d1i_conv.hpp - 1x1 / stride 1 convolution with MANY input channels (1024 / 2048: the K-heavy pointwise layers of the bottleneck
+// networks - ResNeXt-101's 1024 -> 512 at 14 x 14, the 2048-channel layers at 7 x 7; the template also builds for 512), gfx950 MFMA: d3i_conv.hpp's loop with
 // the activation operand STREAMED through LDS instead of resident in it.
 //
 // Replaces: nn.Conv2d(Cin -> Cout, 1x1) + nn.BatchNorm2d(eval) + activation of ConvBlock.forward (reference pytorchcv/models/common/conv.py:

@@ -57,8 +57,6 @@ extern template __global__ void d3i_kernel<PCV_BF16, 256>(const D3Params);
 extern template __global__ void d3i_kernel<PCV_F16, 256>(const D3Params);
 extern template __global__ void d3i_kernel<PCV_BF16, 512>(const D3Params);
 extern template __global__ void d3i_kernel<PCV_F16, 512>(const D3Params);
-extern template __global__ void d1i_kernel<PCV_BF16, 512>(const D3Params);
-extern template __global__ void d1i_kernel<PCV_F16, 512>(const D3Params);
 extern template __global__ void d1i_kernel<PCV_BF16, 1024>(const D3Params);
 extern template __global__ void d1i_kernel<PCV_F16, 1024>(const D3Params);
 extern template __global__ void d1i_kernel<PCV_BF16, 2048>(const D3Params);
@@ -89,7 +87,7 @@ struct pcv_ctx {
     int use_p1r = -1;           // 1x1 kernel with register-resident weights (p1r_conv.hpp; 256 / 512 input channels): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3k = -1;           // 128-input-channel dense 3x3 kernel on 28-wide maps (d3k_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies
     int use_d3i = -1;           // dense 3x3 kernel with the image(s) in LDS (d3i_conv.hpp; 256 input channels on maps up to 14 x 14, 512 up to 7 x 7): -1 = where it applies and fills 3/4 of the chip, 0 = never, 1 = wherever it applies
-    int use_d1i = -1;           // 1x1 kernel for 512 / 1024 / 2048 input channels with streamed activations and weights straight from L2 (d1i_conv.hpp): -1 = where it applies and pays, 0 = never, 1 = wherever it applies
+    int use_d1i = -1;           // 1x1 kernel for 1024 / 2048 input channels with streamed activations and weights straight from L2 (d1i_conv.hpp): -1 = where it applies and pays, 0 = never, 1 = wherever it applies
     int use_d3c = -1;           // 64-input-channel dense 3x3 kernel on 56-wide maps (d3c_conv.hpp): -1 = where it applies and fills the chip, 0 = never, 1 = wherever it applies, 3 = the same without the split tail round (A/B)
     int use_d3w = -1;           // large-tile dense 3x3 kernel (d3w_conv.hpp): -1 = pick_d3w, 0 = never, n > 0 = force shape n - 1
     int dbg_flags = 0;          // timing experiments only ("dbg"): handed to the kernels that read it (d3q_conv.hpp: D3Params::dbgflags)
@@ -158,7 +156,7 @@ struct ConvPlan {
     int gconv_kt = 5;         // K-steps per slab of that blob: 5 (tap pairs x 16 channels; 4/8/16 channels per group) or 9 (taps x 32 channels)
     bool gconv = false;       // grouped 3x3/p1, stride 1 or 2, 4/8/16/32 channels per group: a second blob for gconv3x3(r).hpp follows the generic
     bool d3i = false;         // dense 3x3/s1/p1, 16 bit, 256 / 512 input channels, Cout % 64 == 0: a fragment-ordered copy of the weights for d3i_conv.hpp
-    bool d1i = false;         // 1x1/s1, 16 bit, 512 / 1024 / 2048 input channels, Cout % 64 == 0: the same fragment-ordered copy for d1i_conv.hpp
+    bool d1i = false;         // 1x1/s1, 16 bit, 1024 / 2048 input channels, Cout % 64 == 0: the same fragment-ordered copy for d1i_conv.hpp
     size_t d3i_off = 0;       // follows the generic blob (whether a launch takes that kernel depends on the map size)
     size_t gconv_off = 0;     // one (the choice between the two kernels depends on the map width, known only at launch)
     std::vector<uint32_t> ktab;   // built only when tables == true
@@ -265,7 +263,7 @@ static const char* plan_conv(const pcv_conv_desc& d, ConvPlan& P, bool tables) {
         P.total_bytes = P.d3i_off + (size_t)(d.Cout / D3ICfg::CW) * (d.Cin == 256 ? D3ICfgT<256>::WBYTES : D3ICfgT<512>::WBYTES);
     }
     P.d1i = !P.conv3 && !P.pair && !P.stem && P.ES == 2 && d.kh == 1 && d.kw == 1 && d.groups == 1 && d.stride_h == 1 && d.stride_w == 1 &&
-            d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 && d.pad_r == 0 && (d.Cin == 512 || d.Cin == 1024 || d.Cin == 2048) &&
+            d.pad_t == 0 && d.pad_l == 0 && d.pad_b == 0 && d.pad_r == 0 && (d.Cin == 1024 || d.Cin == 2048) &&
             d.Cout % 64 == 0 && d.out_dtype == d.dtype && P.wrows >= d.Cout && P.Kpad == d.Cin && P.ngb == 1;
     if (P.d1i) {
         P.d3i_off = (P.total_bytes + 15) / 16 * 16;
@@ -496,8 +494,7 @@ static const int kD3WCount = (int)(sizeof(kD3W) / sizeof(kD3W[0]));
 static const void* kD3C[2] = {reinterpret_cast<const void*>(d3c_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3c_kernel<PCV_F16>)};
 static const void* kD3I[2][2] = {{reinterpret_cast<const void*>(d3i_kernel<PCV_BF16, 256>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16, 256>)},
                                  {reinterpret_cast<const void*>(d3i_kernel<PCV_BF16, 512>), reinterpret_cast<const void*>(d3i_kernel<PCV_F16, 512>)}};
-static const void* kD1I[3][2] = {{reinterpret_cast<const void*>(d1i_kernel<PCV_BF16, 512>), reinterpret_cast<const void*>(d1i_kernel<PCV_F16, 512>)},
-                                 {reinterpret_cast<const void*>(d1i_kernel<PCV_BF16, 1024>), reinterpret_cast<const void*>(d1i_kernel<PCV_F16, 1024>)},
+static const void* kD1I[2][2] = {{reinterpret_cast<const void*>(d1i_kernel<PCV_BF16, 1024>), reinterpret_cast<const void*>(d1i_kernel<PCV_F16, 1024>)},
                                  {reinterpret_cast<const void*>(d1i_kernel<PCV_BF16, 2048>), reinterpret_cast<const void*>(d1i_kernel<PCV_F16, 2048>)}};
 static const void* kD3K[2] = {reinterpret_cast<const void*>(d3k_kernel<PCV_BF16>), reinterpret_cast<const void*>(d3k_kernel<PCV_F16>)};
 // p1r_conv.hpp: [0] 256 input channels (8 waves x 64 channels), [1] 512 input channels (8 waves x 32 channels), [2] 256 input channels with
@@ -511,8 +508,8 @@ static int enable_d3x3(pcv_ctx* ctx) {
         for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kP1R[i].fn[t], hipFuncAttributeMaxDynamicSharedMemorySize, kP1R[i].lds));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3C[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3CCfg::LDS));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3K[t], hipFuncAttributeMaxDynamicSharedMemorySize, D3KCfg::LDS));
-    for (int i = 0; i < 3; ++i)
-        for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD1I[i][t], hipFuncAttributeMaxDynamicSharedMemorySize, D1ICfgT<512>::LDS));
+    for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD1I[i][t], hipFuncAttributeMaxDynamicSharedMemorySize, D1ICfgT<1024>::LDS));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[0][t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfgT<256>::LDS));
     for (int t = 0; t < 2; ++t) HIP_TRY(ctx, hipFuncSetAttribute(kD3I[1][t], hipFuncAttributeMaxDynamicSharedMemorySize, D3ICfgT<512>::LDS));
     for (int i = 0; i < kD3WCount; ++i)
@@ -1228,7 +1225,7 @@ enum ConvKernel {
     CK_GCONV_ROWS,  // gconv3x3r.hpp: grouped 3x3, stride 2 or 32 channels per group
     CK_GCONV_FLAT,  // gconv3x3.hpp: grouped 3x3, stride 1, 4 / 8 / 16 channels per group
     CK_D3I,         // d3i_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 256 input channels on maps up to 14 x 14 or 512 up to 7 x 7 (image(s) in LDS, weights straight to registers)
-    CK_D1I,         // d1i_conv.hpp: 1x1 / s1, 16 bit, 512 / 1024 / 2048 input channels (activations streamed through LDS, weights straight to registers)
+    CK_D1I,         // d1i_conv.hpp: 1x1 / s1, 16 bit, 1024 / 2048 input channels (activations streamed through LDS, weights straight to registers)
     CK_D3K,         // d3k_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 128 input channels on 28-wide maps (weights in registers / AGPRs)
     CK_D3C,         // d3c_conv.hpp: dense 3x3 / s1 / p1, 16 bit, 64 input channels on 56-wide maps (weights in registers)
     CK_D3W,         // d3w_conv.hpp: dense 3x3 / s1 / p1, 16 bit, large tiles (eight self-loading waves)
@@ -1347,9 +1344,9 @@ static ConvRoute route_conv(const pcv_ctx* ctx, const pcv_conv_desc* d, const Co
         d->stride_h == d->stride_w && d->stride_h <= 2 && d->pad_t == 0 && d->pad_l == 0 && d->pad_b == 0 && d->pad_r == 0 && d->groups == 1 &&
         G.cpitch == d->Cin && G.wpitch == d->W && d->Cin % 64 == 0 && d->Cout % 8 == 0 && clamp_acts && A.scale && A.shift &&
         G.M64 * (unsigned long long)d->Cout * 2ull < 0x80000000ull) {
-        // 512 / 1024 / 2048 input channels at stride 1: 208-pixel x 256-channel blocks with the weights straight from L2
+        // 1024 / 2048 input channels at stride 1: 208-pixel x 256-channel blocks with the weights straight from L2
         if (P.d1i && ctx->use_d1i != 0 && (ctx->use_d1x1 < 0 || ctx->use_d1i > 0) && G.xbytes < 0x80000000ull) {
-            const long long tiles = ((long long)G.M64 + D1ICfgT<512>::BP - 1) / D1ICfgT<512>::BP * ((d->Cout + 255) / 256);
+            const long long tiles = ((long long)G.M64 + D1ICfgT<1024>::BP - 1) / D1ICfgT<1024>::BP * ((d->Cout + 255) / 256);
             // automatic: from 1024 input channels, without a skip tensor (its epilogue is exposed: 512 -> 1024 + skip 109 against p1r's 74 us,
             // 1024 -> 2048 + skip at 7 x 7 equal), from three quarters of a round of the CUs (2048 -> 512 at 7 x 7: 122 tiles, 47 against 37 us)
             if (ctx->use_d1i > 0 || (d->Cin >= 1024 && !d->has_residual && 4 * tiles >= 3ll * ctx->num_cu)) { R.kernel = CK_D1I; return R; }
@@ -1598,13 +1595,13 @@ static int launch_d1i(pcv_ctx* ctx, const pcv_conv_desc* d, const ConvPlan& P, c
     q.nk = d->Cin / 64; q.slices = q.nk;
     q.act = d->act; q.post_act = d->post_act;
     q.nChTiles = (d->Cout + 255) / 256;
-    const long long nT = ((long long)G.M64 + D1ICfgT<512>::BP - 1) / D1ICfgT<512>::BP * q.nChTiles;
+    const long long nT = ((long long)G.M64 + D1ICfgT<1024>::BP - 1) / D1ICfgT<1024>::BP * q.nChTiles;
     if (nT >= 0x7FFFFFFFll) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_conv2d_fused: too many tiles; split the batch");
     q.nTiles = (int)nT;
     q.dbg = reinterpret_cast<uint32_t*>(ctx->dbg_ptr);       // (diagnostic builds: -DD1I_CYCLES)
     void* args[] = {&q};
-    const int ci = d->Cin == 512 ? 0 : (d->Cin == 1024 ? 1 : 2);
-    HIP_TRY(ctx, hipLaunchKernel(kD1I[ci][d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nT), dim3(256), args, (size_t)D1ICfgT<512>::LDS, A.stream));
+    const int ci = d->Cin == 1024 ? 0 : 1;
+    HIP_TRY(ctx, hipLaunchKernel(kD1I[ci][d->dtype == PCV_BF16 ? 0 : 1], dim3((unsigned)nT), dim3(256), args, (size_t)D1ICfgT<1024>::LDS, A.stream));
     return PCV_OK;
 }
 

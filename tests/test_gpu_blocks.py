@@ -844,17 +844,17 @@ def test_conv1x1_register_weights_kernel_equals_generic_and_oracle(shape, dtype,
     assert bool((d <= 1e-2 * torch.clamp(ref.abs(), min=1.0)).all()), float(d.max())
 
 
-_D1I_SHAPES = [  # (N, Cin, Cout, H, W, residual): 512 / 1024 / 2048 input channels at stride 1 (csrc/d1i_conv.hpp: activations streamed through
-    # LDS in 64-channel slices, weights straight from L2): whole and partial 208-pixel tiles, one to four / ragged channel tiles
-    (3, 1024, 512, 14, 14, False), (4, 512, 1024, 14, 14, True), (5, 2048, 1024, 7, 7, False), (2, 1024, 256, 14, 14, True), (1, 1024, 2048, 7, 7, True),
-    (1, 512, 64, 13, 16, False), (2, 2048, 512, 7, 7, True), (1, 1024, 320, 1, 1, False), (3, 512, 192, 9, 23, True), (2, 1024, 1024, 20, 21, False),
+_D1I_SHAPES = [  # (N, Cin, Cout, H, W, residual): 1024 / 2048 input channels at stride 1 (csrc/d1i_conv.hpp: activations streamed through LDS in
+    # 64-channel slices, weights straight from L2): whole and partial 208-pixel tiles, one to eight / ragged channel tiles
+    (3, 1024, 512, 14, 14, False), (4, 1024, 1024, 14, 14, True), (5, 2048, 1024, 7, 7, False), (2, 1024, 256, 14, 14, True), (1, 1024, 2048, 7, 7, True),
+    (1, 1024, 64, 13, 16, False), (2, 2048, 512, 7, 7, True), (1, 1024, 320, 1, 1, False), (3, 2048, 192, 9, 23, True), (2, 1024, 1024, 20, 21, False),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", _D1I_SHAPES, ids=["x".join(str(int(v)) for v in s) for s in _D1I_SHAPES])
 def test_conv1x1_streamed_kernel_equals_generic_and_oracle(shape, dtype, cuda_device):
-    """d1i_kernel (1x1 / stride 1 with 512 / 1024 / 2048 input channels: ResBottleneck / ResNeXtBottleneck conv1 and conv3, reference
+    """d1i_kernel (1x1 / stride 1 with 1024 / 2048 input channels: ResBottleneck / ResNeXtBottleneck conv1 and conv3, reference
     resnet.py:108-131, resnext.py:56-75): bit-identical to the generic implicit GEMM (same K order, same MFMA chain per accumulator; weights
     from the fragment-ordered copy of the packed blob, activations through a four-slice LDS ring) on whole and partial pixel tiles, one to
     four and ragged channel tiles, with and without the residual epilogue; and within the 16-bit bound of the quantisation-matched oracle."""

@@ -76,7 +76,9 @@ def test_packed_state_broadcast_carries_what_the_kernels_read(name, rccl_group, 
     fp32_state = sum(t.numel() * t.element_size() for t in a.state_dict().values())
     assert msgs >= 1 and nbytes == sum(t.numel() * t.element_size() for t in tb)
     if name == "resnet50":
-        assert 0.45 * fp32_state < nbytes < 0.60 * fp32_state, (nbytes, fp32_state)  # 51 MB of packed state vs 102 MB of fp32
+        # 51 MB of 16-bit packed state + 28 MB of second copies in MFMA-fragment order for d3i / d1i (the 256- / 512-channel 3x3 and the
+        # 1024- / 2048-channel 1x1 layers) vs 102 MB of fp32
+        assert 0.45 * fp32_state < nbytes < 0.85 * fp32_state, (nbytes, fp32_state)
     with torch.no_grad():
         assert torch.equal(b(x), ya)
 
