@@ -50,7 +50,11 @@ template <int CIN_> struct D1ICfgT {
 // MFMA) + 8.6 K of epilogue, two rounds of blocks: 64 us against 69 - 74 on d3q's 1x1 mode; with the activations from L2 (bit 16) 55.6 us -
 // vmcnt retires in order, so every weight load (an L2 hit) issued behind a slice's activation loads waits for HBM. Tried against that, both
 // slower (K loop 35.0 K cycles): one fragment register set refilled behind its last reader + a five-K-half weight look-ahead; a 16-entry
-// fragment ring (program order MFMAs | write | read per pixel block) + the same look-ahead.
+// fragment ring (program order MFMAs | write | read per pixel block) + the same look-ahead. Also tried and dropped: a PERSISTENT form whose slice
+// stream runs across tile boundaries (the last slices of a tile request, write and publish the first slices of the next: no prologue after a
+// block's first tile; bit-identical on resident and 8-block grids) - 67 against 64-68 us, 1024 -> 256 39.9 against 36.4: the two slice register
+// sets that must survive the epilogue push the register allocator over 256 + 48 spare AGPRs, and what it spills are slice registers whose loads
+// have just been issued (load, s_waitcnt vmcnt(0), scratch store: a wait for HBM per tile).
 #ifndef D1I_DBG
 #define D1I_DBG 0
 #endif
