@@ -125,7 +125,10 @@ int pcv_preprocess_u8(pcv_ctx* ctx, const unsigned char* x, void* y, int N, int 
 /* Size of the packed-weight blob of a dense or grouped conv (groups < Cin). */
 int pcv_conv_packed_bytes(const pcv_conv_desc* d, size_t* bytes);
 /* w: fp32 OIHW [Cout, Cin/groups, kh, kw] exactly as `conv.weight` in the reference state_dict (conv.py:250-258)
- * -> packed: K-major, MFMA-row-ordered blob in d->dtype (layout in DESIGN.md). N/H/W of d are ignored. */
+ * -> packed: K-major, MFMA-row-ordered blob in d->dtype (layout in DESIGN.md). N/H/W of d are ignored. For the 16-bit layers that the
+ * image-resident kernels can take (dense 3x3 / s1 / p1 with 256 or 512 input channels, 1x1 / s1 with 1024 or 2048, Cout % 64 == 0) the
+ * blob continues with the same weights in MFMA-fragment load order (csrc/d3i_conv.hpp, csrc/d1i_conv.hpp): about twice the bytes for
+ * those layers - always size the buffer with pcv_conv_packed_bytes. */
 int pcv_conv_pack(pcv_ctx* ctx, const pcv_conv_desc* d, const float* w, void* packed, void* stream);
 /* Depthwise (groups == Cin == Cout, conv.py:437-473): w fp32 [C,1,kh,kw] -> packed [kh*kw][C] in dtype. For 16-bit 3x3 filters the
  * blob continues (from the next 16-byte boundary) with the same taps as the compressed diagonal fragments of the sparse matrix
