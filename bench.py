@@ -65,7 +65,7 @@ def kernel_class_of(name: str):
         return None
     if "d3w_kernel" in name or "d3c_kernel" in name or "d3k_kernel" in name or "d3i_kernel" in name:
         return "dense3x3"
-    if "p1r_kernel" in name:
+    if "p1r_kernel" in name or "d1i_kernel" in name:
         return "dense1x1_kheavy"
     if "d3q_kernel" in name:
         return "dense1x1_kheavy" if head.endswith("true>") else "dense3x3"

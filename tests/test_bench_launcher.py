@@ -107,6 +107,7 @@ def test_kernel_class_of_names():
     assert f("void d3q_kernel<1, 8, 1, 2, 7, 2, true>(D3Params)") == "dense1x1_kheavy"
     assert f("void d3w_kernel<1, 4, 2, 4, 7, 2, 3>(D3Params)") == "dense3x3" and f("void d3c_kernel<1>(D3Params)") == "dense3x3"
     assert f("void p1r_kernel<1, 32, 512>(D3Params)") == "dense1x1_kheavy" and f("void d3k_kernel<1>(D3Params)") == "dense3x3"
+    assert f("void d1i_kernel<1, 1024>(D3Params)") == "dense1x1_kheavy"
     assert f("void d3i_kernel<1, 256>(D3Params)") == "dense3x3" and f("pack_d3i_kernel(unsigned int __vector(4) const*, ...)") is None
     assert f("void igemm_conv_kernel<1, 1, 4, 4, 2, 2, false, 9>(IgemmParams)") == "dense3x3"
     assert f("void igemm_conv_kernel<1, 1, 4, 4, 4, 1, false, 1>(IgemmParams)") == "dense1x1"
