@@ -104,11 +104,13 @@ __device__ __forceinline__ void d3i_body(const D3Params& p, char* smem) {
     const bool has_res = p.res != nullptr;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, has_res ? p.res_bytes : 0u, 0x00020000);
 
-    // ---- weights: A fragments of this wave's 64 channels, K-half kh: 4 x 1 KB at (chTile * 4 + wave) * WBYTES + kh * 4096 (rows past the
-    // blob - a ragged last channel tile - are out of range: zeros) ----
+    // ---- weights: A fragments of this wave's 64 channels, K-half kh: 4 x 1 KB at (chTile * 4 + wave) * WBYTES + kh * 4096 ----
     frag Wf[G::WRING][4];
-    const uint32_t wlane = (uint32_t)(lane * 16);
-    const uint32_t wbase = (uint32_t)((chTile * 4 + wave) * G::WBYTES);
+    // (a wave whose 64 channels lie behind Cout - a ragged last channel tile - loads nothing: its per-lane offset is out of range by itself.
+    // The scalar offset that selects the wave's fragments is not part of the descriptor's range check.)
+    const bool wok = (chTile * 4 + wave) * G::CW < p.Cout;
+    const uint32_t wlane = wok ? (uint32_t)(lane * 16) : 0x80000000u;
+    const uint32_t wbase = wok ? (uint32_t)((chTile * 4 + wave) * G::WBYTES) : 0u;
     auto wload = [&](int kh, auto SLc) __attribute__((always_inline)) {
         constexpr int sl = decltype(SLc)::value;
 #pragma unroll
