@@ -30,7 +30,7 @@ extern "C" {
 /* 2: pcv_conv_desc starts with struct_size and ends with y_cpitch (version 1 had neither check; a binding built against
  * another layout is refused with PCV_ERR_INVALID instead of being read past its end)
  * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count, + pcv_rccl_* (no layout change) */
-#define PCV_ABI_VERSION 3
+#define PCV_ABI_VERSION 4
 
 typedef struct pcv_ctx pcv_ctx;
 

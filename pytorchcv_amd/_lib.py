@@ -24,7 +24,7 @@ class PcvError(RuntimeError):
         self.code = code
 
 
-PCV_ABI_VERSION = 3
+PCV_ABI_VERSION = 4
 
 
 class ConvDesc(ctypes.Structure):
