@@ -29,7 +29,9 @@ extern "C" {
 
 /* 2: pcv_conv_desc starts with struct_size and ends with y_cpitch (version 1 had neither check; a binding built against
  * another layout is refused with PCV_ERR_INVALID instead of being read past its end)
- * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count, + pcv_rccl_* (no layout change) */
+ * 3: + pcv_fp16_guard_begin / pcv_fp16_guard_end / pcv_fp16_overflow_count, + pcv_rccl_* (no layout change)
+ * 4: no signature or struct change; the packed-weight blobs of 16-bit depthwise 3x3 layers and of the dense layers listed at
+ *    pcv_conv_pack carry a second table, so a blob packed by a version-3 library is too short (size blobs with *_packed_bytes) */
 #define PCV_ABI_VERSION 4
 
 typedef struct pcv_ctx pcv_ctx;
