@@ -63,6 +63,13 @@ static inline __host__ __device__ MbrLds mbr_lds_layout(int nrt, int nChunks, in
 #endif
 
 constexpr int kMbrCols = 14;                            // output columns of a wave tile (window = 16 columns = one MFMA pixel block)
+// Stride 2 with two projection tiles (Cout <= 32: MobileNetV2's 16 -> 96 -> 24 and 24 -> 144 -> 32, 29 % of its fused-unit time): the window
+// row is split by column PARITY - an even-column pixel block and an odd-column pixel block (csrc/gconv3x3r.hpp does the same) - so that the
+// {left, centre, right} tuple of output column j is {odd lane j, even lane j, odd lane j + 1}: 15 outputs per pixel block instead of 7
+// (the depthwise and projection MFMAs and the D epilogue per output halve, one DPP move instead of two; the expand work per output is
+// the same 32 / 15 against 16 / 7 input columns). Its x fragments double (72 registers), which the four-tile instances do not have.
+constexpr bool mbr_parity_split(int S, int NRT) { return S == 2 && NRT == 2; }
+constexpr int mbr_out_cols(int S, int NRT) { return S == 1 ? kMbrCols : (mbr_parity_split(S, NRT) ? 15 : kMbrCols / 2); }
 
 // v_smfmac_f32_16x16x64_{f16,bf16}: D(16x16) += A(16x64, 2:4 sparse) . B(64x16). Operand layout as measured on gfx950
 // (tests/tools/micro/smfmac_probe.cpp): K = two halves of 32. B lane (column n = l % 16, kq = l / 16) element e (16 per lane): half
@@ -116,7 +123,9 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
     // w0 + 0, 2 .. 12) and every second window row; window row r is filter row 0 of output r / 2 and 2 of r / 2 - 1 (r even) or 1 of
     // (r - 1) / 2 (r odd). 2 RO + 1 window rows, no skip tensor.
     constexpr int NR = S == 1 ? RO + 2 : 2 * RO + 1;    // window rows
-    constexpr int OC = S == 1 ? kMbrCols : kMbrCols / 2; // output columns of a tile
+    constexpr bool PS = mbr_parity_split(S, NRT);        // window rows as an even-column and an odd-column pixel block
+    constexpr int NBK = PS ? 2 : 1;                      // pixel blocks per window row
+    constexpr int OC = mbr_out_cols(S, NRT);             // output columns of a tile
     // fp16 + ReLU6 (MobileNetV2's default mode): E and D are kept as E / 6 and D / 6 in [0, 1], so that BN + rounding + clamp of a pair
     // is TWO instructions, v_fma_mixlo_f16 / v_fma_mixhi_f16 with the clamp modifier (the generic path: two FMAs, a conversion, two
     // packed clamps - and a dependent chain of four where the loop is bound by exactly such chains: removing the 72 DPP moves of a
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 
     // A tile's position, decoded ONCE (three scalar divisions; decoded inside every row load the epilogue's prefetch alone was ~700
     // scalar instructions per tile): image, first output row, this lane's window column and the byte offset of its pixel in window row 0
-    struct TilePos { int n, h0, wi; bool colok; int off0; };
+    struct TilePos { int n, h0, wi; bool colok, colok1; int off0; };        // (PS: wi / colok / off0 of the EVEN block; the odd block is one column to the left)
     auto decode = [&](int t) __attribute__((always_inline)) -> TilePos {
         TilePos T;
         const int tw = t % p.tilesW;
@@ -240,16 +249,17 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         const int th = t2 % p.tilesH;
         T.n = t2 / p.tilesH;
         T.h0 = th * RO;                                                             // first OUTPUT row
-        T.wi = tw * OC * S - 1 + fr;                                                // this lane's INPUT column
+        T.wi = PS ? tw * OC * 2 + 2 * fr : tw * OC * S - 1 + fr;                   // this lane's INPUT column
         T.colok = (t < p.nTiles) & ((unsigned)T.wi < (unsigned)p.W);
+        T.colok1 = PS && (t < p.nTiles) & ((unsigned)(T.wi - 1) < (unsigned)p.W);
         T.off0 = (((T.n * p.H + T.h0 * S - 1) * p.W + T.wi) * p.Cin + 8 * fq) * 2;                          // < 2 GiB: checked by the host
         return T;
     };
     const int rowpitch = p.W * p.Cin * 2;
     // x fragment of window row r (window rows h0 - 1 .. h0 + RO, columns w0 - 1 .. w0 + 14)
-    auto load_x = [&](const TilePos& T, int r, int ks) __attribute__((always_inline)) -> u32x4 {
-        const bool ok = T.colok & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H) & (32 * ks + 8 * fq < p.Cin);
-        return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 + r * rowpitch + 64 * ks) : 0x80000000u, 0, 0);
+    auto load_x = [&](const TilePos& T, int r, int b, int ks) __attribute__((always_inline)) -> u32x4 {        // (b: 0 = the block / the even block, 1 = the odd block)
+        const bool ok = (b ? T.colok1 : T.colok) & ((unsigned)(T.h0 * S - 1 + r) < (unsigned)p.H) & (32 * ks + 8 * fq < p.Cin);
+        return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (uint32_t)(T.off0 - b * p.Cin * 2 + r * rowpitch + 64 * ks) : 0x80000000u, 0, 0);
     };
 
     // fragments of half-chunk pass h = 2 c + g that do not live in LDS
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
     // 6, 7 stay zero (as fresh values per row they cost two v_mov per tuple plus the compiler's tuple copies: 62 of a chunk's 320 VALU)
     u32x8 RT[2] = {(u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, (u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}};
     TilePos cur = decode(tile);
-    u32x4 xr[XL ? 1 : NR][KA];
+    u32x4 xr[XL ? 1 : NR][NBK][KA];
     // XL: this wave's two x buffers, [row][lane] 16 B each; a row is one LDS-DMA piece (out-of-range lanes are written as zeros)
     typedef __attribute__((address_space(3))) char lds_char;
     char* const xs = smem + L.xs + wave * 2 * NR * 1024;
@@ -293,7 +303,9 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #pragma unroll
             for (int r = 0; r < NR; ++r)
 #pragma unroll
-                for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(cur, r, ks);
+                for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                    for (int ks = 0; ks < KA; ++ks) xr[r][b][ks] = load_x(cur, r, b, ks);
         }
     }
 
@@ -302,6 +314,8 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         const TilePos nxt = decode(ntile);
         const int n = cur.n, h0 = cur.h0, wi = cur.wi;
         const bool colok = (unsigned)wi < (unsigned)p.W;
+        const bool colok1 = PS && (unsigned)(wi - 1) < (unsigned)p.W;
+        const uint32_t cmask[2] = {colok ? 0xFFFFFFFFu : 0u, colok1 ? 0xFFFFFFFFu : 0u};
         if constexpr (XL) {
             // this tile's window has landed: behind its pieces (issued a tile ago) only the previous tile's RO * NRT / 2 stores went out
             // (vmcnt retires in order; a skip tensor that is not x is loaded AND consumed in front of them). Then the next tile's pieces
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                 // BN constants of this lane's 4 channels 32 c + 8 fq + 4 g + e: the same channels in S1 (accumulator rows) and S2
                 f32x4 se = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 8 * fq + 4 * g);
                 f32x4 he = *reinterpret_cast<const f32x4*>(BNs + 128 * c + 32 + 8 * fq + 4 * g);
-                if constexpr (FAST) {                                  // columns outside the image: E = clamp(0 . acc + 0) = 0
+                if constexpr (FAST && !PS) {                           // columns outside the image: E = clamp(0 . acc + 0) = 0 (PS: two blocks, masked below)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         se[e] = colok ? se[e] : 0.f;
@@ -380,29 +394,33 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                     u32x8 fresh = (u32x8){0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
                     u32x8& b8 = KA == 1 ? RT[r & 1] : fresh;             // (two persistent tuples, alternating; with two expand K steps their 16 registers spill)
                     {
+                        uint32_t ob[NBK][2];
+#pragma unroll
+                        for (int bk = 0; bk < NBK; ++bk) {
                         f32x4 e0 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ks = 0; ks < KA; ++ks) {
                             if constexpr (XL) e0 = Mma<DT>::run(we[ks], *reinterpret_cast<const frag*>(xrd + r * 1024), e0);
-                            else e0 = Mma<DT>::run(we[ks], __builtin_bit_cast(frag, xr[r][ks]), e0);
+                            else e0 = Mma<DT>::run(we[ks], __builtin_bit_cast(frag, xr[r][bk][ks]), e0);
                         }
                         // the next tile's row into the registers this S1 used last (rows that are the unit's skip tensor: behind the epilogue)
                         if (!XL && (MBR_DBG & 32) == 0 && g == 1 && last && (!resx || r == 0 || r == NR - 1)) {
 #pragma unroll
-                            for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(nxt, r, ks);
+                            for (int ks = 0; ks < KA; ++ks) xr[r][bk][ks] = load_x(nxt, r, bk, ks);
                         }
-                        uint32_t o[2];
+                        uint32_t* const o = ob[bk];
                         if constexpr (FAST) {
                             const uint32_t rowmask = (unsigned)(h0 * S - 1 + r) < (unsigned)p.H ? 0xFFFFFFFFu : 0u;      // (scalar) rows outside the image
-                            o[0] = mbr_bn_clamp01(e0[0], se[0], he[0], e0[1], se[1], he[1]) & rowmask;
-                            o[1] = mbr_bn_clamp01(e0[2], se[2], he[2], e0[3], se[3], he[3]) & rowmask;
+                            const uint32_t m = PS ? (rowmask & cmask[bk]) : rowmask;
+                            o[0] = mbr_bn_clamp01(e0[0], se[0], he[0], e0[1], se[1], he[1]) & m;
+                            o[1] = mbr_bn_clamp01(e0[2], se[2], he[2], e0[3], se[3], he[3]) & m;
                         } else {
                             // (four v_fma_f32, not two v_pk_fma_f32: beside MFMAs a packed fp32 instruction costs several plain ones -
                             // MI355X_MICROARCH.md, "price of one filler"; mbr_*.hip are built with -fno-slp-vectorize for the same reason)
                             float v[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(e0[e], se[e], he[e]);
-                            const bool ok = colok & ((unsigned)(h0 * S - 1 + r) < (unsigned)p.H);   // E is zero outside the image (the depthwise pads the EXPANDED map)
+                            const bool ok = (bk ? colok1 : colok) & ((unsigned)(h0 * S - 1 + r) < (unsigned)p.H);   // E is zero outside the image (the depthwise pads the EXPANDED map)
                             if constexpr (ACT == PCV_ACT_RELU || ACT == PCV_ACT_RELU6) {
                                 const float hi = ok ? (ACT == PCV_ACT_RELU6 ? 6.f : INFINITY) : 0.f;
 #pragma unroll
@@ -421,12 +439,18 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                             o[0] = __float_as_uint(e0[0]) ^ __float_as_uint(e0[1]);
                             o[1] = __float_as_uint(e0[2]) ^ __float_as_uint(e0[3]);
                         }
-                        if constexpr ((MBR_DBG & 2) != 0) {
-                            b8[0] = o[0]; b8[1] = o[1]; b8[2] = o[0]; b8[3] = o[1]; b8[4] = o[0]; b8[5] = o[1];
+                        }
+                        if constexpr (PS) {
+                            // output column j = lane j: left tap = input column 2 j - 1 = odd lane j, centre = even lane j, right = odd lane j + 1
+                            b8[0] = ob[1][0]; b8[1] = ob[1][1];
+                            b8[2] = ob[0][0]; b8[3] = ob[0][1];
+                            b8[4] = mbr_dpp<0x101>(ob[1][0]); b8[5] = mbr_dpp<0x101>(ob[1][1]);  // row_shl:1
+                        } else if constexpr ((MBR_DBG & 2) != 0) {
+                            b8[0] = ob[0][0]; b8[1] = ob[0][1]; b8[2] = ob[0][0]; b8[3] = ob[0][1]; b8[4] = ob[0][0]; b8[5] = ob[0][1];
                         } else {
-                            b8[0] = mbr_dpp<0x111>(o[0]); b8[1] = mbr_dpp<0x111>(o[1]);          // row_shr:1 = the pixel to the left
-                            b8[2] = o[0]; b8[3] = o[1];
-                            b8[4] = mbr_dpp<0x101>(o[0]); b8[5] = mbr_dpp<0x101>(o[1]);          // row_shl:1 = the pixel to the right
+                            b8[0] = mbr_dpp<0x111>(ob[0][0]); b8[1] = mbr_dpp<0x111>(ob[0][1]);  // row_shr:1 = the pixel to the left
+                            b8[2] = ob[0][0]; b8[3] = ob[0][1];
+                            b8[4] = mbr_dpp<0x101>(ob[0][0]); b8[5] = mbr_dpp<0x101>(ob[0][1]);  // row_shl:1 = the pixel to the right
                         }
                     }
                     // ---- S2: filter row 2 of output row r - 2 (complete behind it), 1 of r - 1, 0 of r ------------------------------------
@@ -488,8 +512,8 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
         F16Guard<DT, true> guard;
         // plain: no activation behind the projection or behind the skip add (every LinearBottleneck): no uniform branches per row
         auto epilogue = [&](auto plain) __attribute__((always_inline)) {
-        const bool lane_out = (fr >= 1) & (fr <= kMbrCols) & colok & (S == 1 || (fr & 1));
-        const int wo = S == 1 ? wi : (wi >> 1);                                   // (stride 2: input column w0 + 2 j = lane 2 j + 1)
+        const bool lane_out = PS ? (fr < OC) : ((fr >= 1) & (fr <= kMbrCols) & colok & (S == 1 || (fr & 1)));
+        const int wo = S == 1 ? wi : (wi >> 1);                                   // (stride 2: input column w0 + 2 j = lane 2 j + 1; parity split: even lane j)
         const float* const BNp = reinterpret_cast<const float*>(smem + L.bnp);
 #pragma unroll
         for (int ipp = 0; ipp < ((MBR_DBG & 4) ? 0 : NRT / 2); ++ipp) {
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
                 if (p.res != nullptr) {                                  // (x as the skip tensor: channels 32 ipp + 8 fq = K step ipp of window row u + 1)
                     u32x4 r4;
                     if constexpr (XL) r4 = resx ? *reinterpret_cast<const u32x4*>(xrd + (u + 1) * 1024) : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
-                    else r4 = resx ? xr[S == 1 ? u + 1 : 0][ipp < KA ? ipp : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
+                    else r4 = resx ? xr[S == 1 ? u + 1 : 0][0][ipp < KA ? ipp : 0] : __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float r0, r1;
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(64 * WAVES) void mbr_kernel(const MbParams p) {
 #pragma unroll
                 for (int r = 1; r <= RO; ++r)
 #pragma unroll
-                    for (int ks = 0; ks < KA; ++ks) xr[r][ks] = load_x(nxt, r, ks);
+                    for (int ks = 0; ks < KA; ++ks) xr[r][0][ks] = load_x(nxt, r, 0, ks);
             }
         }
         guard.commit(p.ovf);

@@ -2294,7 +2294,7 @@ int pcv_mbconv_fused(pcv_ctx* ctx, const pcv_conv_desc* d_exp, const pcv_conv_de
     if (wave_shape && ctx->use_mbr) {
         const MbrEntry* e = pick_mbr(d_dw->dtype, nrt, p.act_e == p.act_d ? p.act_e : -1, S, kaw, p.nChunks);
         if (e) {
-            const int oc = kMbrCols / S;                                        // output columns of a wave tile
+            const int oc = mbr_out_cols(S, e->nrt);                             // output columns of a wave tile
             p.tilesH = (p.Ho + e->ro - 1) / e->ro; p.tilesW = (p.Wo + oc - 1) / oc;
             const long nT = (long)p.N * p.tilesH * p.tilesW;
             if (nT >= 0x7FFFFFFFl) return fail(ctx, PCV_ERR_TOO_LARGE, "pcv_mbconv_fused: too many tiles; split the batch");

@@ -324,6 +324,10 @@ _MB_SHAPES = [  # (N, H, W, Cin, expand?, Cout, stride, act)
     # the register-resident kernel stages their x window through LDS (csrc/mbr.hpp, XL), with and without the skip tensor
     (2, 112, 112, 32, "keep", 16, 1, "relu6"), (3, 30, 27, 16, "keep", 16, 1, "relu6"), (2, 17, 33, 8, "keep", 24, 1, "relu"),
     (5, 14, 14, 32, "keep", 32, 1, "hswish"),
+    # stride 2 with up to 32 projected channels: the register-resident kernel splits the window rows by column parity (15 outputs per pixel
+    # block): odd / even map sizes, widths that end inside a tile's first / last columns
+    (2, 57, 45, 24, True, 32, 2, "relu6"), (3, 31, 30, 16, True, 24, 2, "relu"), (1, 29, 61, 32, True, 16, 2, "relu6"), (2, 30, 31, 24, True, 24, 2, "relu6"),
+    (1, 19, 93, 24, True, 24, 2, "relu6"),
 ]
 
 
