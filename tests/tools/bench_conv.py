@@ -32,6 +32,29 @@ for (N, C, Co, H, k, s, g, res) in LAYERS:
     Ho = (H + 2 * (k // 2) - k) // s + 1
     r = engine.NHWC(torch.randn(N, Ho, Ho, Co, device=dev).to(torch.bfloat16), N, Ho, Ho, Co) if res else None
     times = {v: [] for v in VARIANTS}
+    if os.environ.get("BENCH_GRAPH"):
+        # BENCH_GRAPH=1: 20 launches per variant captured into a hipGraph and replayed - the figure for launches under ~40 us, where the
+        # eager loop below measures the host's launch rate (~28 us per call) instead of the kernel
+        with torch.no_grad():
+            graphs = {}
+            for v, t in VARIANTS.items():
+                tune(t); blk(x, residual=r); torch.cuda.synchronize()
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    for _ in range(20):
+                        y = blk(x, residual=r)
+                graphs[v] = (cg, y)
+            for rnd in range(5):
+                for v, (cg, _) in graphs.items():
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); cg.replay(); e1.record(); torch.cuda.synchronize()
+                    times[v].append(e0.elapsed_time(e1) / 20 * 1e3)
+        Ho_ = (H + 2 * (k // 2) - k) // s + 1
+        flops = 2.0 * N * Ho_ * Ho_ * Co * (C // g) * k * k
+        print("N%d %dx%d C%d->%d k%d s%d g%d%s (graph replay):" % (N, H, H, C, Co, k, s, g, " +res" if res else ""), flush=True)
+        for v, t in times.items():
+            print("    %-12s %7.1f us  %6.0f TF   (min %.1f)" % (v, statistics.median(t), flops / statistics.median(t) / 1e6, min(t)), flush=True)
+        continue
     with torch.no_grad():
         for v, t in VARIANTS.items():
             tune(t); blk(x, residual=r)
